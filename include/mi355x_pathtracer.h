@@ -1,0 +1,174 @@
+/* mi355x_pathtracer.h -- C ABI of the MI355X-native path tracer (libmi355x_pathtracer.so).
+ *
+ * Drop-in boundary for the reference's path-tracing module (nkkk98/MyGPURaytracer, all file:line citations are
+ * relative to the reference root):
+ *
+ *   reference interface                                  this ABI
+ *   ---------------------------------------------------  --------------------------------------------------
+ *   Scene::Scene(filename)            src/scene.cpp:10    ptx_scene_load / ptx_scene_get_* / ptx_scene_free
+ *   runCuda() camera recompute        src/main.cpp:105    ptx_scene_apply_runcuda_camera
+ *   pathtraceInit(Scene*)             src/pathtrace.h:7   ptx_create        (scene flattened to POD, options =
+ *                                     src/pathtrace.cu:101                   the #defines of pathtrace.cu:36-40)
+ *   pathtrace(uchar4* pbo, frame, it) src/pathtrace.h:9   ptx_iterate (+ ptx_write_pbo, ptx_read_image)
+ *                                     src/pathtrace.cu:433
+ *   pathtraceFree()                   src/pathtrace.h:8   ptx_destroy
+ *   timer()                           src/pathtrace.h:6   ptx_last_loop_ms
+ *   checkCUDAError -> exit()          src/pathtrace.cu:42 return codes + ptx_last_error()
+ *
+ * Plain C types only: no C++ classes, no torch types.  Every pointer marked "device" is a HIP device pointer on
+ * the device the handle was created on; everything else is host memory.  The C++ veneer with the reference's
+ * own names (pathtraceInit / pathtrace / pathtraceFree, class Scene) lives in
+ * mygpuraytracer_amd/csrc/pathtrace_api.h and is a few lines over this ABI.
+ */
+#ifndef MI355X_PATHTRACER_H
+#define MI355X_PATHTRACER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_OK 0
+#define PTX_ERR_INVALID 1      /* bad argument / malformed scene                      */
+#define PTX_ERR_IO 2           /* file could not be read                              */
+#define PTX_ERR_HIP 3          /* a HIP runtime call failed (message in ptx_last_error) */
+#define PTX_ERR_NODEVICE 4     /* no usable HIP device: there is no CPU fallback      */
+#define PTX_ERR_UNSUPPORTED 5
+
+/* enum GeomType, src/sceneStructs.h:10-15 */
+enum { PTX_SPHERE = 0, PTX_CUBE = 1, PTX_TRIANGLE = 2, PTX_OBJ = 3 };
+
+/* struct Material, src/sceneStructs.h:71-81 -- same 44-byte layout */
+typedef struct ptx_material {
+    float color[3];
+    float specular_exponent;
+    float specular_color[3];
+    float hasReflective;
+    float hasRefractive;
+    float indexOfRefraction;
+    float emittance;
+} ptx_material;
+
+/* struct Texture, src/sceneStructs.h:36-48 (host pixels; uploaded by ptx_create) */
+typedef struct ptx_texture {
+    int32_t width, height, channels;
+    const uint8_t *image;          /* width*height*channels bytes, or NULL when channels == 0 */
+} ptx_texture;
+
+/* struct Geom, src/sceneStructs.h:50-69.  Matrices in glm memory order (column major, m[c*4+r]).
+ * faces: faceSize x 15 floats = 3 vertices x (position xyz, texcoord uv) -- the only Face fields the path
+ * tracer reads (src/intersections.h:216-262). */
+typedef struct ptx_geom {
+    int32_t type;
+    int32_t materialid;
+    float translation[3], rotation[3], scale[3];
+    float transform[16], inverseTransform[16], invTranspose[16];
+    int32_t faceSize;
+    const float *faces;
+    ptx_texture kd, ks, bump, ke;
+} ptx_geom;
+
+/* struct Camera, src/sceneStructs.h:83-92 */
+typedef struct ptx_camera {
+    int32_t resolution[2];
+    float position[3], lookAt[3], view[3], up[3], right[3];
+    float fov[2];
+    float pixelLength[2];
+} ptx_camera;
+
+/* Runtime form of the compile-time switches of src/pathtrace.cu:36-40 (same defaults via ptx_default_options),
+ * plus the multi-GPU row-tile split.  A device owns the row blocks b (of tile_rows rows each) with
+ * b % tile_world == tile_rank; pixelIndex stays global (x + y*W). */
+typedef struct ptx_options {
+    int32_t depth_of_field;      /* DEPTH_OF_FIELD 0      */
+    int32_t cache_first_bounce;  /* CACHE_FIRST_BOUNCE 1  */
+    int32_t sort_by_material;    /* SORT_BY_MATERIAL 1    */
+    int32_t antialiasing;        /* ANTIALIASING 1        */
+    int32_t bounding_box;        /* BOUNDING_BOX 0 (accepted, must be 0) */
+    int32_t tile_rows, tile_rank, tile_world;   /* 0,0,1 = whole frame */
+    int32_t device;              /* HIP device ordinal, -1 = current device */
+    int32_t reserved[7];
+} ptx_options;
+
+typedef struct ptx_stats {
+    int32_t bounces;                 /* bounce-loop passes of the last iteration                       */
+    int64_t rays_per_bounce[64];     /* paths entering the intersect stage, per bounce (last iteration) */
+    int64_t rays_total;              /* sum over all iterations since create/reset                      */
+    double loop_ms_total;            /* device time of the bounce loops since create/reset              */
+    int64_t iterations;
+} ptx_stats;
+
+typedef struct ptx_tracer ptx_tracer;     /* opaque: one scene on one device */
+typedef struct ptx_scene ptx_scene;       /* opaque: a loaded scenes/<x>.txt  */
+
+const char *ptx_last_error(void);
+int ptx_device_count(void);               /* HIP devices visible; 0 means nothing here can run */
+void ptx_default_options(ptx_options *o);
+
+/* ---- scene loader (src/scene.cpp, src/utilities.cpp) ------------------------------------------------------ */
+/* Paths inside the scene file ("../models/x.obj", mtl search path "../models/materials") resolve relative to
+ * base_dir, which plays the role of the reference's process CWD; NULL = directory of scene_path. */
+int ptx_scene_load(const char *scene_path, const char *base_dir, ptx_scene **out);
+void ptx_scene_free(ptx_scene *s);
+int ptx_scene_num_geoms(const ptx_scene *s);
+int ptx_scene_num_materials(const ptx_scene *s);
+const ptx_geom *ptx_scene_geoms(const ptx_scene *s);
+const ptx_material *ptx_scene_materials(const ptx_scene *s);
+ptx_camera *ptx_scene_camera(ptx_scene *s);            /* mutable: RenderState.camera      */
+int ptx_scene_iterations(const ptx_scene *s);          /* RenderState.iterations           */
+int ptx_scene_trace_depth(const ptx_scene *s);         /* RenderState.traceDepth           */
+void ptx_scene_set_trace_depth(ptx_scene *s, int depth);
+void ptx_scene_set_resolution(ptx_scene *s, int w, int h);   /* re-derives fov/pixelLength as loadCamera does */
+const char *ptx_scene_image_name(const ptx_scene *s);  /* RenderState.imageName            */
+void ptx_scene_apply_runcuda_camera(ptx_scene *s);     /* src/main.cpp:56-70 + :105-123    */
+
+/* ---- tracer ------------------------------------------------------------------------------------------------ */
+/* pathtraceInit.  external_image: optional device buffer of W*H*3 floats to accumulate into (caller keeps
+ * ownership, e.g. a torch tensor that is later reduced over RCCL); NULL = the tracer allocates and zeroes one.
+ * stream: optional hipStream_t to run on; NULL = the tracer creates its own. */
+int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
+               const ptx_camera *camera, int trace_depth, const ptx_options *options,
+               float *external_image, void *stream, ptx_tracer **out);
+int ptx_create_from_scene(const ptx_scene *s, const ptx_options *options, float *external_image, void *stream,
+                          ptx_tracer **out);
+void ptx_destroy(ptx_tracer *t);                        /* pathtraceFree; NULL is a no-op */
+
+int ptx_set_camera(ptx_tracer *t, const ptx_camera *camera, int trace_depth);  /* camera edits without re-init */
+int ptx_reset_image(ptx_tracer *t);
+
+/* One iteration of pathtrace() (iter is 1-based and seeds the RNG).  Enqueues on the tracer's stream and
+ * returns without waiting; any read entry point below synchronises. */
+int ptx_iterate(ptx_tracer *t, int iter);
+/* iterations iter_first .. iter_first+count-1 back to back, no host round trip in between */
+int ptx_render(ptx_tracer *t, int iter_first, int count);
+int ptx_synchronize(ptx_tracer *t);
+
+int ptx_read_image(ptx_tracer *t, float *host_rgb);     /* W*H*3 floats = sum over iterations (state.image) */
+float *ptx_device_image(ptx_tracer *t);                 /* device pointer of the accumulation buffer        */
+int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba);          /* sendImageToPBO, pathtrace.cu:69 */
+int ptx_write_pbo_device(ptx_tracer *t, int iter, void *device_uchar4);
+double ptx_last_loop_ms(ptx_tracer *t);                 /* timer(): bounce loop of the last iteration       */
+int ptx_get_stats(ptx_tracer *t, ptx_stats *out);
+int ptx_owned_pixels(const ptx_tracer *t);              /* pixels this tracer generates (tile split)        */
+void *ptx_stream(ptx_tracer *t);
+
+/* ---- per-stage entry points (parity tests; same record layouts as the reference's PathSegment 44 B and
+ *      ShadeableIntersection 32 B, host arrays in/out, the work runs on the device) --------------------------- */
+int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out10);
+int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32);
+int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void *isects32, void *paths44);
+int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44);             /* all W*H camera rays */
+int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *cos_out,
+                 const double *pw_in, double *pow5_out, const float *powf_xy, float *powf_out);
+/* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
+ * of the next iteration(s). */
+int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
+/* fields15 (optional): 15 rows of min(n, cap) floats: ox oy oz dx dy dz cr cg cb t nx ny nz u v */
+int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx,
+                          int32_t *material, float *fields15, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

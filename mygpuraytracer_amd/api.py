@@ -1,0 +1,454 @@
+"""ctypes host side over the C ABI of libmi355x_pathtracer.so (include/mi355x_pathtracer.h,
+include/mi355x_stream_compaction.h).
+
+Mirrors the reference's interface for the path (nkkk98/MyGPURaytracer):
+
+* ``Scene(path)``                      <->  ``new Scene(sceneFile)``                (src/scene.cpp:10, src/main.cpp:47)
+* ``Scene.apply_runcuda_camera()``     <->  first ``runCuda()`` camera recompute    (src/main.cpp:105-123)
+* ``Tracer(scene, options)``           <->  ``pathtraceInit(scene)``                (src/pathtrace.cu:101)
+* ``Tracer.pathtrace(iter)``           <->  ``pathtrace(pbo, frame, iter)``         (src/pathtrace.cu:433)
+* ``Tracer.close()``                   <->  ``pathtraceFree()``                     (src/pathtrace.cu:159)
+* ``Tracer.last_loop_ms()``            <->  ``timer().getGpuElapsedTimeForPreviousOperation()``
+* ``StreamCompaction.*``               <->  ``StreamCompaction::{CPU,Naive,Efficient,Thrust}::*``
+
+Nothing here computes: every call goes through the library, and there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmi355x_pathtracer.so")
+
+PTX_OK = 0
+vp = C.c_void_p
+
+
+class PathTracerError(RuntimeError):
+    pass
+
+
+class Material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("specular_exponent", C.c_float), ("specular_color", C.c_float * 3),
+                ("hasReflective", C.c_float), ("hasRefractive", C.c_float), ("indexOfRefraction", C.c_float),
+                ("emittance", C.c_float)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("image", C.POINTER(C.c_uint8))]
+
+
+class Geom(C.Structure):
+    _fields_ = [("type", C.c_int32), ("materialid", C.c_int32),
+                ("translation", C.c_float * 3), ("rotation", C.c_float * 3), ("scale", C.c_float * 3),
+                ("transform", C.c_float * 16), ("inverseTransform", C.c_float * 16), ("invTranspose", C.c_float * 16),
+                ("faceSize", C.c_int32), ("faces", C.POINTER(C.c_float)),
+                ("kd", Texture), ("ks", Texture), ("bump", Texture), ("ke", Texture)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("resolution", C.c_int32 * 2), ("position", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("view", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("fov", C.c_float * 2),
+                ("pixelLength", C.c_float * 2)]
+
+
+class Options(C.Structure):
+    """Runtime form of the #defines of src/pathtrace.cu:36-40 (+ the multi-GPU row-tile split)."""
+    _fields_ = [("depth_of_field", C.c_int32), ("cache_first_bounce", C.c_int32), ("sort_by_material", C.c_int32),
+                ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
+                ("tile_rows", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("bounces", C.c_int32), ("rays_per_bounce", C.c_int64 * 64), ("rays_total", C.c_int64),
+                ("loop_ms_total", C.c_double), ("iterations", C.c_int64)]
+
+
+def build_library(force=False):
+    """Compiles the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG_DIR, "csrc")])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the native library; raises loudly when it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PathTracerError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C mygpuraytracer_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i, f = C.c_int, C.c_float
+    L.ptx_last_error.restype = C.c_char_p
+    L.ptx_device_count.restype = i
+    L.ptx_default_options.argtypes = [C.POINTER(Options)]
+    L.ptx_scene_load.restype, L.ptx_scene_load.argtypes = i, [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.ptx_scene_free.argtypes = [vp]
+    L.ptx_scene_num_geoms.restype, L.ptx_scene_num_geoms.argtypes = i, [vp]
+    L.ptx_scene_num_materials.restype, L.ptx_scene_num_materials.argtypes = i, [vp]
+    L.ptx_scene_geoms.restype, L.ptx_scene_geoms.argtypes = C.POINTER(Geom), [vp]
+    L.ptx_scene_materials.restype, L.ptx_scene_materials.argtypes = C.POINTER(Material), [vp]
+    L.ptx_scene_camera.restype, L.ptx_scene_camera.argtypes = C.POINTER(Camera), [vp]
+    L.ptx_scene_iterations.restype, L.ptx_scene_iterations.argtypes = i, [vp]
+    L.ptx_scene_trace_depth.restype, L.ptx_scene_trace_depth.argtypes = i, [vp]
+    L.ptx_scene_set_trace_depth.argtypes = [vp, i]
+    L.ptx_scene_set_resolution.argtypes = [vp, i, i]
+    L.ptx_scene_image_name.restype, L.ptx_scene_image_name.argtypes = C.c_char_p, [vp]
+    L.ptx_scene_apply_runcuda_camera.argtypes = [vp]
+    L.ptx_create.restype = i
+    L.ptx_create.argtypes = [i, C.POINTER(Geom), i, C.POINTER(Material), C.POINTER(Camera), i, C.POINTER(Options), vp,
+                             vp, C.POINTER(vp)]
+    L.ptx_create_from_scene.restype = i
+    L.ptx_create_from_scene.argtypes = [vp, C.POINTER(Options), vp, vp, C.POINTER(vp)]
+    L.ptx_destroy.argtypes = [vp]
+    L.ptx_set_camera.restype, L.ptx_set_camera.argtypes = i, [vp, C.POINTER(Camera), i]
+    L.ptx_reset_image.restype, L.ptx_reset_image.argtypes = i, [vp]
+    L.ptx_iterate.restype, L.ptx_iterate.argtypes = i, [vp, i]
+    L.ptx_render.restype, L.ptx_render.argtypes = i, [vp, i, i]
+    L.ptx_synchronize.restype, L.ptx_synchronize.argtypes = i, [vp]
+    L.ptx_read_image.restype, L.ptx_read_image.argtypes = i, [vp, vp]
+    L.ptx_device_image.restype, L.ptx_device_image.argtypes = vp, [vp]
+    L.ptx_write_pbo.restype, L.ptx_write_pbo.argtypes = i, [vp, i, vp]
+    L.ptx_write_pbo_device.restype, L.ptx_write_pbo_device.argtypes = i, [vp, i, vp]
+    L.ptx_last_loop_ms.restype, L.ptx_last_loop_ms.argtypes = C.c_double, [vp]
+    L.ptx_get_stats.restype, L.ptx_get_stats.argtypes = i, [vp, C.POINTER(Stats)]
+    L.ptx_owned_pixels.restype, L.ptx_owned_pixels.argtypes = i, [vp]
+    L.ptx_stream.restype, L.ptx_stream.argtypes = vp, [vp]
+    L.ptx_kat_geom_test.restype, L.ptx_kat_geom_test.argtypes = i, [vp, i, i, vp, vp]
+    L.ptx_kat_compute_intersections.restype, L.ptx_kat_compute_intersections.argtypes = i, [vp, i, vp, vp]
+    L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
+    L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
+    L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    L.ptx_debug_set_capture.restype, L.ptx_debug_set_capture.argtypes = i, [vp, i]
+    L.ptx_debug_read_stream.restype, L.ptx_debug_read_stream.argtypes = i, [vp, C.POINTER(i), vp, vp, vp, vp, i]
+    # stream compaction
+    L.sc_cpu_scan.argtypes = [i, vp, vp]
+    for n in ("sc_cpu_compact_without_scan", "sc_cpu_compact_with_scan", "sc_efficient_compact", "sc_naive_scan",
+              "sc_efficient_scan", "sc_thrust_scan"):
+        getattr(L, n).restype, getattr(L, n).argtypes = i, [i, vp, vp]
+    L.sc_scan_workspace_bytes.restype, L.sc_scan_workspace_bytes.argtypes = C.c_ulonglong, [i]
+    L.sc_scan_device.restype, L.sc_scan_device.argtypes = i, [i, vp, vp, vp, vp]
+    L.sc_compact_device.restype, L.sc_compact_device.argtypes = i, [i, vp, vp, vp, vp, vp]
+    L.sc_last_gpu_ms.restype = f
+    L.sc_last_cpu_ms.restype = f
+    L.sc_ilog2.restype, L.sc_ilog2.argtypes = i, [i]
+    L.sc_ilog2ceil.restype, L.sc_ilog2ceil.argtypes = i, [i]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != PTX_OK:
+        raise PathTracerError("%s failed (code %d): %s" % (what, rc, load_library().ptx_last_error().decode()))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(vp)
+
+
+def default_options(**kw):
+    o = Options()
+    load_library().ptx_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class Scene:
+    """A loaded scenes/*.txt (class Scene, src/scene.h)."""
+
+    def __init__(self, path, base_dir=None, res=None, depth=None):
+        self.lib = load_library()
+        h = vp()
+        _check(self.lib.ptx_scene_load(os.fspath(path).encode(), base_dir.encode() if base_dir else None, C.byref(h)),
+               "ptx_scene_load(%s)" % path)
+        self.h = h
+        if res is not None:
+            self.set_resolution(*res)
+        if depth is not None:
+            self.set_trace_depth(depth)
+
+    def close(self):
+        if self.h:
+            self.lib.ptx_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_geoms(self):
+        return self.lib.ptx_scene_num_geoms(self.h)
+
+    @property
+    def num_materials(self):
+        return self.lib.ptx_scene_num_materials(self.h)
+
+    @property
+    def camera(self):
+        return self.lib.ptx_scene_camera(self.h).contents
+
+    @property
+    def resolution(self):
+        c = self.camera
+        return int(c.resolution[0]), int(c.resolution[1])
+
+    @property
+    def iterations(self):
+        return self.lib.ptx_scene_iterations(self.h)
+
+    @property
+    def trace_depth(self):
+        return self.lib.ptx_scene_trace_depth(self.h)
+
+    @property
+    def image_name(self):
+        return self.lib.ptx_scene_image_name(self.h).decode()
+
+    def set_trace_depth(self, d):
+        self.lib.ptx_scene_set_trace_depth(self.h, d)
+
+    def set_resolution(self, w, h):
+        self.lib.ptx_scene_set_resolution(self.h, w, h)
+
+    def apply_runcuda_camera(self):
+        self.lib.ptx_scene_apply_runcuda_camera(self.h)
+
+    def dump(self):
+        """POD view of the scene as numpy arrays (same dict layout the CPU checkers use in tests/cpulibs.py)."""
+        ng, nm = self.num_geoms, self.num_materials
+        geoms = self.lib.ptx_scene_geoms(self.h)
+        mats = self.lib.ptx_scene_materials(self.h)
+        gints = np.zeros((ng, 3), np.int32)
+        trs = np.zeros((ng, 9), np.float32)
+        gm = np.zeros((ng, 48), np.float32)
+        faces, textures = [], {}
+        for i in range(ng):
+            g = geoms[i]
+            gints[i] = (g.type, g.materialid, g.faceSize)
+            trs[i] = list(g.translation) + list(g.rotation) + list(g.scale)
+            gm[i] = list(g.transform) + list(g.inverseTransform) + list(g.invTranspose)
+            if g.faceSize:
+                faces.append(np.ctypeslib.as_array(g.faces, shape=(g.faceSize, 15)).copy())
+            else:
+                faces.append(np.zeros((0, 15), np.float32))
+            for which, t in enumerate((g.kd, g.ks, g.ke, g.bump)):      # checker order: kd, ks, ke, bump
+                if t.channels:
+                    textures[(i, which)] = np.ctypeslib.as_array(t.image, shape=(t.height, t.width, t.channels)).copy()
+        m = np.zeros((nm, 11), np.float32)
+        for i in range(nm):
+            m[i] = np.frombuffer(bytes(mats[i]), np.float32)
+        c = self.camera
+        cf = np.array(list(c.position) + list(c.lookAt) + list(c.view) + list(c.up) + list(c.right) + list(c.fov)
+                      + list(c.pixelLength), np.float32)
+        ci = np.array([c.resolution[0], c.resolution[1], self.iterations, self.trace_depth], np.int32)
+        return dict(geom_ints=gints, geom_trs=trs, geom_mats=gm, materials=m, faces=faces, cam_ints=ci, cam_floats=cf,
+                    textures=textures)
+
+
+class Tracer:
+    """pathtraceInit / pathtrace / pathtraceFree on one device (opaque ptx_tracer)."""
+
+    def __init__(self, scene, options=None, external_image_ptr=None, stream_ptr=None, **opt_kw):
+        self.lib = load_library()
+        if self.lib.ptx_device_count() < 1:
+            raise PathTracerError("no HIP device is visible; the path tracer has no CPU path")
+        self.options = options if options is not None else default_options(**opt_kw)
+        h = vp()
+        _check(self.lib.ptx_create_from_scene(scene.h, C.byref(self.options), external_image_ptr, stream_ptr, C.byref(h)),
+               "ptx_create")
+        self.h = h
+        self.width, self.height = scene.resolution
+        self.trace_depth = scene.trace_depth
+        self.iteration = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ptx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # --- the reference's per-frame call -----------------------------------------------------------------
+    def pathtrace(self, iteration, read_image=False):
+        _check(self.lib.ptx_iterate(self.h, iteration), "ptx_iterate")
+        self.iteration = iteration
+        return self.read_image() if read_image else None
+
+    def render(self, iter_first, count):
+        _check(self.lib.ptx_render(self.h, iter_first, count), "ptx_render")
+        self.iteration = iter_first + count - 1
+
+    def synchronize(self):
+        _check(self.lib.ptx_synchronize(self.h), "ptx_synchronize")
+
+    def set_camera(self, scene):
+        _check(self.lib.ptx_set_camera(self.h, C.byref(scene.camera), scene.trace_depth), "ptx_set_camera")
+
+    def reset_image(self):
+        _check(self.lib.ptx_reset_image(self.h), "ptx_reset_image")
+
+    def read_image(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        _check(self.lib.ptx_read_image(self.h, _ptr(out)), "ptx_read_image")
+        return out
+
+    def pbo(self, iteration):
+        out = np.zeros((self.width * self.height, 4), np.uint8)
+        _check(self.lib.ptx_write_pbo(self.h, iteration, _ptr(out)), "ptx_write_pbo")
+        return out
+
+    def device_image_ptr(self):
+        return self.lib.ptx_device_image(self.h)
+
+    def stream_ptr(self):
+        return self.lib.ptx_stream(self.h)
+
+    def last_loop_ms(self):
+        return float(self.lib.ptx_last_loop_ms(self.h))
+
+    def owned_pixels(self):
+        return self.lib.ptx_owned_pixels(self.h)
+
+    def stats(self):
+        s = Stats()
+        _check(self.lib.ptx_get_stats(self.h, C.byref(s)), "ptx_get_stats")
+        return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations))
+
+    # --- per-stage entry points used by the parity tests --------------------------------------------------
+    def geom_test(self, gi, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 10), np.float32)
+        _check(self.lib.ptx_kat_geom_test(self.h, gi, len(rays), _ptr(rays), _ptr(out)), "ptx_kat_geom_test")
+        return out
+
+    def compute_intersections(self, paths):
+        paths = np.ascontiguousarray(paths)
+        assert paths.dtype.itemsize == 44
+        out = np.zeros(len(paths), np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4"),
+                                             ("texcoord", "<f4", 2), ("geomId", "<i4")]))
+        _check(self.lib.ptx_kat_compute_intersections(self.h, len(paths), _ptr(paths), _ptr(out)), "ptx_kat_compute_intersections")
+        return out
+
+    def shade(self, iteration, idx, isects, paths):
+        paths = np.array(paths, copy=True)
+        isects = np.ascontiguousarray(isects)
+        idx = np.ascontiguousarray(idx, np.int32)
+        assert paths.dtype.itemsize == 44 and isects.dtype.itemsize == 32
+        _check(self.lib.ptx_kat_shade(self.h, iteration, len(paths), _ptr(idx), _ptr(isects), _ptr(paths)), "ptx_kat_shade")
+        return paths
+
+    def generate(self, iteration):
+        out = np.zeros(self.width * self.height, np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("color", "<f4", 3),
+                                                            ("pixelIndex", "<i4"), ("remainingBounces", "<i4")]))
+        _check(self.lib.ptx_kat_generate(self.h, iteration, _ptr(out)), "ptx_kat_generate")
+        return out
+
+    def libm(self, x, pw, pxy):
+        x = np.ascontiguousarray(x, np.float32)
+        pw = np.ascontiguousarray(pw, np.float64)
+        pxy = np.ascontiguousarray(pxy, np.float32).reshape(-1, 2)
+        n = len(x)
+        assert len(pw) == n and len(pxy) == n
+        s, c, po = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        p5 = np.zeros(n, np.float64)
+        _check(self.lib.ptx_kat_libm(self.h, n, _ptr(x), _ptr(s), _ptr(c), _ptr(pw), _ptr(p5), _ptr(pxy), _ptr(po)), "ptx_kat_libm")
+        return s, c, p5, po
+
+    def debug_capture(self, bounce):
+        _check(self.lib.ptx_debug_set_capture(self.h, bounce), "ptx_debug_set_capture")
+
+    def debug_stream(self):
+        cap = self.width * self.height
+        pix, idx, mat = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int(0)
+        _check(self.lib.ptx_debug_read_stream(self.h, C.byref(n), _ptr(pix), _ptr(idx), _ptr(mat), None, 0), "ptx_debug_read_stream")
+        m = n.value
+        fields = np.zeros((15, max(m, 1)), np.float32)
+        _check(self.lib.ptx_debug_read_stream(self.h, C.byref(n), _ptr(pix), _ptr(idx), _ptr(mat), _ptr(fields), m), "ptx_debug_read_stream")
+        names = ("ox", "oy", "oz", "dx", "dy", "dz", "cr", "cg", "cb", "t", "nx", "ny", "nz", "u", "v")
+        out = dict(pix=pix[:m].copy(), idx=idx[:m].copy(), mat=mat[:m].copy())
+        for k, nm in enumerate(names):
+            out[nm] = fields[k, :m].copy()
+        return out
+
+
+class StreamCompaction:
+    """namespace StreamCompaction (stream_compaction/*.cu): host arrays in, host arrays out."""
+
+    def __init__(self):
+        self.lib = load_library()
+
+    def _scan(self, fn, a):
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros_like(a)
+        rc = fn(len(a), _ptr(out), _ptr(a))
+        if rc:
+            _check(rc, fn.__name__)
+        return out
+
+    def cpu_scan(self, a):
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros_like(a)
+        self.lib.sc_cpu_scan(len(a), _ptr(out), _ptr(a))
+        return out
+
+    def cpu_compact_without_scan(self, a):
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros_like(a)
+        n = self.lib.sc_cpu_compact_without_scan(len(a), _ptr(out), _ptr(a))
+        return out[:n].copy()
+
+    def cpu_compact_with_scan(self, a):
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros_like(a)
+        n = self.lib.sc_cpu_compact_with_scan(len(a), _ptr(out), _ptr(a))
+        return out[:n].copy()
+
+    def naive_scan(self, a):
+        return self._scan(self.lib.sc_naive_scan, a)
+
+    def efficient_scan(self, a):
+        return self._scan(self.lib.sc_efficient_scan, a)
+
+    def thrust_scan(self, a):
+        return self._scan(self.lib.sc_thrust_scan, a)
+
+    def efficient_compact(self, a):
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros_like(a)
+        n = self.lib.sc_efficient_compact(len(a), _ptr(out), _ptr(a))
+        if n < 0:
+            raise PathTracerError("sc_efficient_compact failed: %s" % self.lib.ptx_last_error().decode())
+        return out[:n].copy()
+
+    def last_gpu_ms(self):
+        return float(self.lib.sc_last_gpu_ms())
+
+    def last_cpu_ms(self):
+        return float(self.lib.sc_last_cpu_ms())

@@ -1,0 +1,85 @@
+// pathtrace_api.cpp -- the reference's four free functions (src/pathtrace.h:6-9) over the C ABI.
+// Keeps the reference's module-static, one-scene-per-process contract (src/pathtrace.cu:91-98) and its
+// print-and-exit error policy (checkCUDAError, src/pathtrace.cu:42-60); the C ABI underneath returns codes.
+#include "pathtrace_api.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace {
+Scene *hst_scene = nullptr;          // borrowed, must outlive pathtraceFree (src/pathtrace.cu:91,102)
+ptx_tracer *g_tracer = nullptr;
+ptx_options g_options;
+bool g_options_init = false;
+
+void check(int rc, const char *what) {
+    if (rc == PTX_OK) return;
+    fprintf(stderr, "mi355x pathtracer error (%s): %s\n", what, ptx_last_error());
+    exit(EXIT_FAILURE);
+}
+}  // namespace
+
+Scene::Scene(const std::string &filename, const std::string &base_dir) : impl_(nullptr) {
+    int rc = ptx_scene_load(filename.c_str(), base_dir.empty() ? nullptr : base_dir.c_str(), &impl_);
+    if (rc != PTX_OK) throw std::runtime_error(std::string("Scene: ") + ptx_last_error());
+    int ng = ptx_scene_num_geoms(impl_), nm = ptx_scene_num_materials(impl_);
+    if (ng) geoms.assign(ptx_scene_geoms(impl_), ptx_scene_geoms(impl_) + ng);
+    if (nm) materials.assign(ptx_scene_materials(impl_), ptx_scene_materials(impl_) + nm);
+    state.camera = *ptx_scene_camera(impl_);
+    state.iterations = (unsigned)ptx_scene_iterations(impl_);
+    state.traceDepth = ptx_scene_trace_depth(impl_);
+    state.imageName = ptx_scene_image_name(impl_);
+    state.image.assign((size_t)state.camera.resolution[0] * state.camera.resolution[1], mi355x::vec3{0.f, 0.f, 0.f});
+}
+
+Scene::~Scene() { ptx_scene_free(impl_); }
+
+void Scene::applyRunCudaCamera() {
+    *ptx_scene_camera(impl_) = state.camera;
+    ptx_scene_apply_runcuda_camera(impl_);
+    state.camera = *ptx_scene_camera(impl_);
+}
+
+void Scene::setResolution(int w, int h) {
+    ptx_scene_set_resolution(impl_, w, h);
+    state.camera = *ptx_scene_camera(impl_);
+    state.image.assign((size_t)w * h, mi355x::vec3{0.f, 0.f, 0.f});
+}
+
+ptx_options &pathtraceOptions() {
+    if (!g_options_init) { ptx_default_options(&g_options); g_options_init = true; }
+    return g_options;
+}
+
+PerformanceTimer &timer() {
+    static PerformanceTimer t;
+    return t;
+}
+
+float PerformanceTimer::getGpuElapsedTimeForPreviousOperation() { return g_tracer ? (float)ptx_last_loop_ms(g_tracer) : 0.f; }
+
+void pathtraceInit(Scene *scene) {
+    hst_scene = scene;
+    check(ptx_create((int)scene->geoms.size(), scene->geoms.data(), (int)scene->materials.size(), scene->materials.data(),
+                     &scene->state.camera, scene->state.traceDepth, &pathtraceOptions(), nullptr, nullptr, &g_tracer),
+          "pathtraceInit");
+}
+
+void pathtraceFree() {          // safe before init and idempotent, as main.cpp:129 relies on
+    ptx_destroy(g_tracer);
+    g_tracer = nullptr;
+}
+
+void pathtrace(uchar4 *pbo, int frame, int iter) {
+    (void)frame;                 // unused by the reference as well
+    if (!g_tracer || !hst_scene) { fprintf(stderr, "pathtrace called before pathtraceInit\n"); exit(EXIT_FAILURE); }
+    // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
+    check(ptx_set_camera(g_tracer, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
+    check(ptx_iterate(g_tracer, iter), "pathtrace");
+    check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");
+    check(ptx_read_image(g_tracer, &hst_scene->state.image[0].x), "image readback");     // :555-556
+}
+
+ptx_tracer *pathtraceHandle() { return g_tracer; }

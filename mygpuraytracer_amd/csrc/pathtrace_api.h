@@ -1,0 +1,69 @@
+// pathtrace_api.h -- C++ veneer with the reference's own names over the C ABI (include/mi355x_pathtracer.h).
+//
+// A maintainer of the reference replaces `#include "pathtrace.h"` / `#include "scene.h"` by this header and links
+// libmi355x_pathtracer.so; main.cpp's calls (src/main.cpp:47, :128-148) compile unchanged in meaning:
+//
+//     scene = new Scene(sceneFile);                       // src/scene.cpp:10
+//     pathtraceFree(); pathtraceInit(scene);              // src/pathtrace.h:7-8
+//     pathtrace(pbo_dptr, frame, iteration);              // src/pathtrace.h:9 ; fills scene->state.image
+//     timer().getGpuElapsedTimeForPreviousOperation();    // src/timer.h
+//
+// glm is not required: vec3 members are plain float[3]-compatible structs with the same memory layout.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/mi355x_pathtracer.h"
+
+struct uchar4;          // HIP's vector type; the pbo argument is a device pointer exactly as in the reference
+
+namespace mi355x {
+struct vec3 { float x, y, z; };
+}
+
+typedef ptx_geom Geom;            // src/sceneStructs.h:50-69 (POD subset the tracer reads)
+typedef ptx_material Material;    // src/sceneStructs.h:71-81
+typedef ptx_camera Camera;        // src/sceneStructs.h:83-92
+
+// src/sceneStructs.h:94-100
+struct RenderState {
+    Camera camera;
+    unsigned int iterations;
+    int traceDepth;
+    std::vector<mi355x::vec3> image;      // sum of per-iteration radiance, row-major x + y*W, y = 0 on top
+    std::string imageName;
+};
+
+// src/scene.h:11-32
+class Scene {
+public:
+    // base_dir plays the role of the reference's process CWD for "../models/..." paths; "" = directory of filename
+    explicit Scene(const std::string &filename, const std::string &base_dir = "");
+    ~Scene();
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+    std::vector<Geom> geoms;
+    std::vector<Material> materials;
+    RenderState state;
+    ptx_scene *handle() const { return impl_; }
+    void applyRunCudaCamera();            // src/main.cpp:56-70 + 105-123 (what the first runCuda() call does)
+    void setResolution(int w, int h);     // harness override of RES (re-derives fov / pixelLength as loadCamera does)
+private:
+    ptx_scene *impl_;
+};
+
+// src/timer.h:17-100 -- only the GPU half is meaningful here
+class PerformanceTimer {
+public:
+    float getGpuElapsedTimeForPreviousOperation();
+    float getCpuElapsedTimeForPreviousOperation() { return 0.f; }
+};
+
+// Runtime form of the #defines in src/pathtrace.cu:36-40; read by the next pathtraceInit.
+ptx_options &pathtraceOptions();
+
+PerformanceTimer &timer();                              // src/pathtrace.h:6
+void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7
+void pathtraceFree();                                   // src/pathtrace.h:8
+void pathtrace(uchar4 *pbo, int frame, int iteration);  // src/pathtrace.h:9 ; pbo may be NULL (no preview)
+ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state

@@ -1,0 +1,598 @@
+// pt_device.h -- device-side arithmetic of the MI355X path tracer (gfx950, wave64).
+//
+// Every function states which reference function it computes (file:line relative to the reference root).
+// Result parity with the reference is a *bit-level* requirement here, not a tolerance: the shading RNG is seeded
+// by a path's position in the material-sorted stream (src/pathtrace.cu:373), so one flipped hit/miss shifts
+// every later stream index of that bounce.  Hence:
+//   * this translation unit is compiled with -ffp-contract=off (no FMA contraction), IEEE division and sqrt
+//     (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), f32 denormals on;
+//   * each expression is written in the order glm 0.9.6.3 evaluates it, e.g. mat4*vec4 is
+//     (m0*x + m1*y) + (m2*z + m3*w)  (glm/detail/type_mat4x4.inl:617-628);
+//   * sin/cos/pow are not the hardware approximations but the portable binary64 routines below, which agree with
+//     glibc's correctly rounded results (tests/test_own_libm.py) and run the same on host and device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_DEV __device__ __forceinline__
+
+namespace ptd {
+
+struct vec3 { float x, y, z; };
+
+PT_DEV vec3 V3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV vec3 add(vec3 a, vec3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV vec3 sub(vec3 a, vec3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV vec3 mul(vec3 a, vec3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV vec3 scale(vec3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+PT_DEV vec3 neg(vec3 a) { return V3(-a.x, -a.y, -a.z); }
+// glm dot(vec3): tmp = x*y; tmp.x + tmp.y + tmp.z   (glm/detail/func_geometric.inl:65-72)
+PT_DEV float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// glm cross (func_geometric.inl:134-141)
+PT_DEV vec3 cross(vec3 x, vec3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+// glm normalize = x * (1 / sqrt(dot(x,x)))  (func_geometric.inl:154-159, func_exponential.inl:62-68)
+PT_DEV vec3 normalize(vec3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
+PT_DEV float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
+PT_DEV float fmin_glm(float x, float y) { return x < y ? x : y; }   // glm min: x < y ? x : y
+PT_DEV float fmax_glm(float x, float y) { return x > y ? x : y; }   // glm max: x > y ? x : y
+
+// multiplyMV (src/intersections.h:34-36): xyz of mat4*vec4, glm column-major m[c*4+r]
+PT_DEV vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
+    vec3 r;
+    r.x = (m[0] * v.x + m[4] * v.y) + (m[8] * v.z + m[12] * w);
+    r.y = (m[1] * v.x + m[5] * v.y) + (m[9] * v.z + m[13] * w);
+    r.z = (m[2] * v.x + m[6] * v.y) + (m[10] * v.z + m[14] * w);
+    return r;
+}
+
+// ---- portable libm (same operation sequence as the CPU checker's copy; binary64, one rounding to binary32) ----
+// sin and cos of a float argument, |x| <= 1e5: Cody-Waite reduction by pi/2, Taylor polynomials.
+PT_DEV void sincos_own(float xf, float *s, float *c) {
+    const double INVPIO2 = 0x1.45f306dc9c883p-1;
+    const double PIO2_1 = 0x1.921fb54400000p+0;
+    const double PIO2_1T = 0x1.0b4611a626331p-34;
+    double x = (double)xf;
+    if (!(x >= -1.0e5 && x <= 1.0e5)) { *s = __builtin_nanf(""); *c = __builtin_nanf(""); return; }
+    double y = x * INVPIO2;
+    int k = (int)(y + (y >= 0.0 ? 0.5 : -0.5));
+    double kd = (double)k;
+    double r = (x - kd * PIO2_1) - kd * PIO2_1T;
+    double z = r * r;
+    double ps = -0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49;
+    ps = 0x1.6124613a86d09p-33 + z * ps;
+    ps = -0x1.ae64567f544e4p-26 + z * ps;
+    ps = 0x1.71de3a556c734p-19 + z * ps;
+    ps = -0x1.a01a01a01a01ap-13 + z * ps;
+    ps = 0x1.1111111111111p-7 + z * ps;
+    ps = -0x1.5555555555555p-3 + z * ps;
+    double sr = r + r * (z * ps);
+    double pc = -0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45;
+    pc = 0x1.1eed8eff8d898p-29 + z * pc;
+    pc = -0x1.27e4fb7789f5cp-22 + z * pc;
+    pc = 0x1.a01a01a01a01ap-16 + z * pc;
+    pc = -0x1.6c16c16c16c17p-10 + z * pc;
+    pc = 0x1.5555555555555p-5 + z * pc;
+    pc = -0x1.0000000000000p-1 + z * pc;
+    double cr = 1.0 + z * pc;
+    double sd, cd;
+    switch (k & 3) {
+    case 0: sd = sr; cd = cr; break;
+    case 1: sd = cr; cd = -sr; break;
+    case 2: sd = -sr; cd = -cr; break;
+    default: sd = -cr; cd = sr; break;
+    }
+    *s = (float)sd;
+    *c = (float)cd;
+}
+
+PT_DEV double pow5_own(double x) {
+    double x2 = x * x;
+    double x4 = x2 * x2;
+    return x4 * x;
+}
+
+// powf(x, y) for x >= 0 via exp(y*log(x)) in binary64; powf(x, 0) = 1 for every x.
+PT_DEV float powf_own(float xf, float yf) {
+    if (yf == 0.0f) return 1.0f;
+    if (xf != xf || yf != yf) return __builtin_nanf("");
+    if (xf == 1.0f) return 1.0f;
+    if (xf < 0.0f) return __builtin_nanf("");
+    if (xf == 0.0f) return yf > 0.0f ? 0.0f : __builtin_inff();
+    if (__builtin_isinf(xf)) return yf > 0.0f ? __builtin_inff() : 0.0f;
+    if (__builtin_isinf(yf)) return ((xf > 1.0f) == (yf > 0.0f)) ? __builtin_inff() : 0.0f;
+    double x = (double)xf;
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((long long)((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    if (m > 0x1.6a09e667f3bcdp+0) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 0x1.af286bca1af28p-4 + z * 0x1.8618618618618p-4;
+    p = 0x1.e1e1e1e1e1e1ep-4 + z * p;
+    p = 0x1.1111111111111p-3 + z * p;
+    p = 0x1.3b13b13b13b14p-3 + z * p;
+    p = 0x1.745d1745d1746p-3 + z * p;
+    p = 0x1.c71c71c71c71cp-3 + z * p;
+    p = 0x1.2492492492492p-2 + z * p;
+    p = 0x1.999999999999ap-2 + z * p;
+    p = 0x1.5555555555555p-1 + z * p;
+    double logm = 2.0 * s + s * (z * p);
+    const double LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
+    double ed = (double)e;
+    double lg = (ed * LN2_HI + logm) + ed * LN2_LO;
+    double a = (double)yf * lg;
+    if (a > 89.0) return __builtin_inff();
+    if (a < -104.0) return 0.0f;
+    double kk = a * 0x1.71547652b82fep+0;
+    int k = (int)(kk + (kk >= 0.0 ? 0.5 : -0.5));
+    double kd = (double)k;
+    double r = (a - kd * LN2_HI) - kd * LN2_LO;
+    double q = 0x1.1eed8eff8d898p-29 + r * 0x1.6124613a86d09p-33;
+    q = 0x1.ae64567f544e4p-26 + r * q;
+    q = 0x1.27e4fb7789f5cp-22 + r * q;
+    q = 0x1.71de3a556c734p-19 + r * q;
+    q = 0x1.a01a01a01a01ap-16 + r * q;
+    q = 0x1.a01a01a01a01ap-13 + r * q;
+    q = 0x1.6c16c16c16c17p-10 + r * q;
+    q = 0x1.1111111111111p-7 + r * q;
+    q = 0x1.5555555555555p-5 + r * q;
+    q = 0x1.5555555555555p-3 + r * q;
+    q = 0x1.0000000000000p-1 + r * q;
+    double er = 1.0 + (r + r * (r * q));
+    double two_k = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    return (float)(er * two_k);
+}
+
+// ---- hash + RNG -----------------------------------------------------------------------------------------------
+// utilhash, src/intersections.h:12-20
+PT_DEV uint32_t utilhash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+// thrust::minstd_rand (a = 48271, m = 2^31 - 1) + thrust::uniform_real_distribution<float>
+struct Rng {
+    uint32_t x;
+    // makeSeededRandomEngine, src/pathtrace.cu:62-66
+    PT_DEV void seed(int iter, int index, int depth) {
+        uint32_t h = utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
+        x = h % 2147483647u;
+        if (x == 0) x = 1;
+    }
+    PT_DEV uint32_t next() {
+        uint64_t p = (uint64_t)x * 48271u;                       // < 2^47
+        uint32_t r = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);   // p mod (2^31-1) by folding
+        r = (r & 0x7fffffffu) + (r >> 31);
+        if (r >= 2147483647u) r -= 2147483647u;
+        x = r;
+        return r;
+    }
+    // float(x - min) / (1.0f + float(max - min)) * (b - a) + a, min = 1, max = m - 1: the divisor is 2^31
+    PT_DEV float uniform(float a, float b) {
+        float result = (float)(next() - 1u);
+        result /= 2147483648.0f;
+        return (result * (b - a)) + a;
+    }
+};
+
+// ---- scene on the device ---------------------------------------------------------------------------------------
+struct DTex { int32_t w, h, ch, pad; uint64_t off; };    // off = byte offset into the texture blob
+struct DGeom {
+    float xf[16], inv[16], invT[16];    // transform, inverseTransform, invTranspose (glm memory order)
+    int32_t type, materialid, faceStart, faceCount;
+    DTex tex[4];                        // kd, ks, ke, bump
+};
+struct DMaterial {                      // = struct Material, src/sceneStructs.h:71-81
+    float color[3];
+    float exponent;
+    float speccolor[3];
+    float hasReflective, hasRefractive, ior, emittance;
+};
+struct DCamera {                        // = struct Camera, src/sceneStructs.h:83-92
+    int32_t resx, resy;
+    float position[3], lookAt[3], view[3], up[3], right[3], fov[2], pixelLength[2];
+};
+struct DScene {
+    const DGeom *__restrict__ geoms;
+    const DMaterial *__restrict__ mats;
+    const float *__restrict__ faces;    // 15 floats per face: 3 x (pos xyz, uv)
+    const uint8_t *__restrict__ texels;
+    int32_t ngeoms, nmats;
+};
+
+enum { G_SPHERE = 0, G_CUBE = 1, G_TRIANGLE = 2, G_OBJ = 3 };
+
+struct Ray { vec3 o, d; };
+
+// getPointOnRay, src/intersections.h:27-29
+PT_DEV vec3 getPointOnRay(Ray r, float t) {
+    vec3 nd = normalize(r.d);
+    float tt = t - .0001f;
+    return add(r.o, V3(tt * nd.x, tt * nd.y, tt * nd.z));
+}
+
+// boxIntersectionTest, src/intersections.h:48-90.  Returns t (world distance) or -1.
+PT_DEV float boxIntersectionTest(const DGeom &box, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+    Ray q;
+    q.o = multiplyMV(box.inv, r.o, 1.0f);
+    q.d = normalize(multiplyMV(box.inv, r.d, 0.0f));
+    float tmin = -1e38f, tmax = 1e38f;
+    int tmin_axis = -1, tmax_axis = -1;      // which component of the zero-initialised glm::vec3 n is set
+    float tmin_s = 0.f, tmax_s = 0.f;        // and its value (+1 / -1)
+    const float qo[3] = {q.o.x, q.o.y, q.o.z};
+    const float qd[3] = {q.d.x, q.d.y, q.d.z};
+#pragma unroll
+    for (int xyz = 0; xyz < 3; ++xyz) {
+        float t1 = (-0.5f - qo[xyz]) / qd[xyz];
+        float t2 = (+0.5f - qo[xyz]) / qd[xyz];
+        float ta = fmin_glm(t1, t2);
+        float tb = fmax_glm(t1, t2);
+        float ns = t2 < t1 ? +1.f : -1.f;
+        if (ta > 0 && ta > tmin) { tmin = ta; tmin_axis = xyz; tmin_s = ns; }
+        if (tb < tmax) { tmax = tb; tmax_axis = xyz; tmax_s = ns; }
+    }
+    if (tmax >= tmin && tmax > 0) {
+        outside = true;
+        if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; outside = false; }
+        point = multiplyMV(box.xf, getPointOnRay(q, tmin), 1.0f);
+        vec3 n = V3(tmin_axis == 0 ? tmin_s : 0.f, tmin_axis == 1 ? tmin_s : 0.f, tmin_axis == 2 ? tmin_s : 0.f);
+        normal = normalize(multiplyMV(box.invT, n, 0.0f));
+        return length(sub(r.o, point));
+    }
+    return -1.f;
+}
+
+// sphereIntersectionTest, src/intersections.h:102-144
+PT_DEV float sphereIntersectionTest(const DGeom &sphere, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+    const float radius = .5f;
+    Ray rt;
+    rt.o = multiplyMV(sphere.inv, r.o, 1.0f);
+    rt.d = normalize(multiplyMV(sphere.inv, r.d, 0.0f));
+    float vDotDirection = dot(rt.o, rt.d);
+    float radicand = vDotDirection * vDotDirection - (dot(rt.o, rt.o) - radius * radius);   // powf(.5f,2) == .25f
+    if (radicand < 0) return -1.f;
+    float squareRoot = __builtin_sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+    float t;
+    if (t1 < 0 && t2 < 0) {
+        return -1.f;
+    } else if (t1 > 0 && t2 > 0) {
+        t = fmin_glm(t1, t2);
+        outside = true;
+    } else {
+        t = fmax_glm(t1, t2);
+        outside = false;
+    }
+    vec3 objP = getPointOnRay(rt, t);
+    point = multiplyMV(sphere.xf, objP, 1.f);
+    normal = normalize(multiplyMV(sphere.invT, objP, 0.f));
+    if (!outside) normal = neg(normal);
+    return length(sub(r.o, point));
+}
+
+// glm::intersectRayTriangle, glm/gtx/intersect.inl:37-74 (single sided: a < epsilon => miss)
+PT_DEV bool intersectRayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 v1, vec3 v2, float &bx, float &by) {
+    vec3 e1 = sub(v1, v0);
+    vec3 e2 = sub(v2, v0);
+    vec3 p = cross(dir, e2);
+    float a = dot(e1, p);
+    if (a < 1.1920928955078125e-07f) return false;     // FLT_EPSILON
+    float f = 1.0f / a;
+    vec3 s = sub(orig, v0);
+    bx = f * dot(s, p);
+    if (bx < 0.0f) return false;
+    if (bx > 1.0f) return false;
+    vec3 q = cross(s, e1);
+    by = f * dot(dir, q);
+    if (by < 0.0f) return false;
+    if (by + bx > 1.0f) return false;
+    float bz = f * dot(e2, q);
+    return bz >= 0.0f;
+}
+
+// Texel read as the reference indexes it (src/interactions.h:172-179): nearest, no wrap.  Indices outside the
+// image (undefined behaviour in the reference) are clamped to the valid byte range.
+PT_DEV uint32_t texel(const DScene &sc, const DTex &t, int pixelID, int c) {
+    long long idx = (long long)pixelID * t.ch + c;
+    long long n = (long long)t.w * t.h * t.ch;
+    if (idx < 0) idx = 0;
+    if (idx >= n) idx = n - 1;
+    return (uint32_t)sc.texels[t.off + (uint64_t)idx];
+}
+
+PT_DEV vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
+
+// meshIntersectionTest, src/intersections.h:207-282.  Returns the OBJECT-space distance, as the reference does.
+PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &geom, Ray r, vec3 &point, vec3 &normal, float &u,
+                                  float &v, bool &outside) {
+    Ray q;
+    q.o = multiplyMV(geom.inv, r.o, 1.0f);
+    q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
+    float tmin = 3.402823466e+38f;     // FLT_MAX
+    int nearest = -1;
+    const float *__restrict__ faces = sc.faces + (size_t)geom.faceStart * 15;
+    for (int j = 0; j < geom.faceCount; j++) {
+        const float *__restrict__ tri = faces + (size_t)j * 15;
+        vec3 p0 = ld3(tri), p1 = ld3(tri + 5), p2 = ld3(tri + 10);
+        float b0, b1;
+        if (intersectRayTriangle(q.o, q.d, p0, p1, p2, b0, b1)) {
+            float w = 1 - b0 - b1;
+            vec3 p = add(add(scale(p0, w), scale(p1, b0)), scale(p2, b1));
+            float t = length(sub(q.o, p));          // glm::distance(p, q.origin)
+            if (t < tmin) {
+                tmin = t;
+                nearest = j;
+                u = (w * tri[3] + b0 * tri[8]) + b1 * tri[13];
+                v = (w * tri[4] + b0 * tri[9]) + b1 * tri[14];
+            }
+        }
+    }
+    if (nearest == -1) return -1.f;
+    vec3 objP = getPointOnRay(q, tmin);
+    const float *__restrict__ tri = faces + (size_t)nearest * 15;
+    vec3 e1 = sub(ld3(tri + 5), ld3(tri));
+    vec3 e2 = sub(ld3(tri + 10), ld3(tri));
+    vec3 objN = normalize(cross(e1, e2));
+    point = multiplyMV(geom.xf, objP, 1.f);
+    normal = normalize(multiplyMV(geom.invT, objN, 0.f));
+    outside = dot(normal, r.d) < 0;
+    const DTex &bump = geom.tex[3];
+    if (geom.type == G_OBJ && bump.ch) {            // tangent-space bump map, :245-279
+        float dUV1x = tri[8] - tri[3], dUV1y = tri[9] - tri[4];
+        float dUV2x = tri[13] - tri[3], dUV2y = tri[14] - tri[4];
+        float f = 1.0f / (dUV1x * dUV2y - dUV2x * dUV1y);
+        vec3 tangent, bitangent;
+        tangent.x = f * (dUV2y * e1.x - dUV1y * e2.x);
+        tangent.y = f * (dUV2y * e1.y - dUV1y * e2.y);
+        tangent.z = f * (dUV2y * e1.z - dUV1y * e2.z);
+        tangent = normalize(tangent);
+        bitangent.x = f * (-dUV2x * e1.x + dUV1x * e2.x);
+        bitangent.y = f * (-dUV2x * e1.y + dUV1x * e2.y);
+        bitangent.z = f * (-dUV2x * e1.z + dUV1x * e2.z);
+        bitangent = normalize(bitangent);
+        vec3 T = normalize(multiplyMV(geom.xf, tangent, 0.f));
+        vec3 B = normalize(multiplyMV(geom.xf, bitangent, 0.f));
+        vec3 N = normal;
+        int coordU = (int)(u * bump.w);
+        int coordV = (int)(v * bump.h);
+        int pixelID = coordV * bump.w + coordU;
+        uint32_t colR = texel(sc, bump, pixelID, 0), colG = texel(sc, bump, pixelID, 1), colB = texel(sc, bump, pixelID, 2);
+        vec3 tsn = normalize(V3(colR / 255.f, colG / 255.f, colB / 255.f));
+        tsn = normalize(V3(tsn.x * 2.0f - 1.0f, tsn.y * 2.0f - 1.0f, tsn.z * 2.0f - 1.0f));
+        vec3 w3 = V3(T.x * tsn.x + B.x * tsn.y + N.x * tsn.z,        // mat3(T,B,N) * v, glm type_mat3x3.inl:487
+                     T.y * tsn.x + B.y * tsn.y + N.y * tsn.z,
+                     T.z * tsn.x + B.z * tsn.y + N.z * tsn.z);
+        normal = normalize(w3);
+    }
+    return tmin;
+}
+
+struct Hit {
+    float t;          // -1 = miss
+    vec3 n;
+    float u, v;
+    int32_t geom, mat;
+};
+
+// body of computeIntersections, src/pathtrace.cu:270-343: nearest t > 0 over all geoms, lowest index wins ties.
+// A miss leaves materialId = 0 (the reference's full-frame memset, :501), which is what the material sort sees.
+PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
+    float t_min = 3.402823466e+38f;
+    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
+    int hit_geom_index = -1;
+    float tmp_u = 0.f, tmp_v = 0.f;
+    for (int i = 0; i < sc.ngeoms; i++) {
+        const DGeom &geom = sc.geoms[i];
+        float t = 0.f;
+        vec3 tmp_p, tmp_n = V3(0.f, 0.f, 0.f);
+        bool outside = true;
+        bool tested = true;
+        if (geom.type == G_CUBE) t = boxIntersectionTest(geom, ray, tmp_p, tmp_n, outside);
+        else if (geom.type == G_SPHERE) t = sphereIntersectionTest(geom, ray, tmp_p, tmp_n, outside);
+        else if (geom.type == G_OBJ) t = meshIntersectionTest(sc, geom, ray, tmp_p, tmp_n, tmp_u, tmp_v, outside);
+        else tested = false;    // TRIANGLE has no test routine in the reference: t keeps a value that never wins
+        if (tested && t > 0.0f && t_min > t) {
+            t_min = t;
+            hit_geom_index = i;
+            h.n = tmp_n;
+            h.u = tmp_u; h.v = tmp_v;
+        }
+    }
+    if (hit_geom_index != -1) {
+        h.t = t_min;
+        h.geom = hit_geom_index;
+        h.mat = sc.geoms[hit_geom_index].materialid;
+    }
+}
+
+// ---- BSDF --------------------------------------------------------------------------------------------------------
+#define PT_TWO_PI 6.2831853071795864769252867665590057683943f            // src/utilities.h:13
+#define PT_SQRT_OF_ONE_THIRD 0.5773502691896257645091487805019574556476f // src/utilities.h:14
+
+// calculateRandomDirectionInHemisphere, src/interactions.h:11-43
+PT_DEV vec3 randomDirectionInHemisphere(vec3 normal, Rng &rng) {
+    float up = __builtin_sqrtf(rng.uniform(0.f, 1.f));
+    float over = __builtin_sqrtf(1 - up * up);
+    float around = rng.uniform(0.f, 1.f) * PT_TWO_PI;
+    vec3 notNormal;
+    if (__builtin_fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) notNormal = V3(1, 0, 0);
+    else if (__builtin_fabsf(normal.y) < PT_SQRT_OF_ONE_THIRD) notNormal = V3(0, 1, 0);
+    else notNormal = V3(0, 0, 1);
+    vec3 perp1 = normalize(cross(normal, notNormal));
+    vec3 perp2 = normalize(cross(normal, perp1));
+    float sn, cs;
+    sincos_own(around, &sn, &cs);
+    vec3 a = scale(normal, up);
+    vec3 b = scale(perp1, cs * over);
+    vec3 c = scale(perp2, sn * over);
+    return add(add(a, b), c);
+}
+
+// glm reflect: I - N * dot(N, I) * 2
+PT_DEV vec3 reflect(vec3 I, vec3 N) { return sub(I, scale(scale(N, dot(N, I)), 2.0f)); }
+// glm refract (func_geometric.inl:190-197)
+PT_DEV vec3 refract(vec3 I, vec3 N, float eta) {
+    float dotValue = dot(N, I);
+    float k = 1.0f - eta * eta * (1.0f - dotValue * dotValue);
+    float f = eta * dotValue + __builtin_sqrtf(k);
+    vec3 r = sub(scale(I, eta), scale(N, f));
+    return scale(r, (float)(k >= 0.0f));
+}
+// Schlick term with the reference's mixed precision (src/interactions.h:151-152, :190-191)
+PT_DEV float schlick(float IoR1, float IoR2, float cosTheta) {
+    float r0 = ((IoR1 - IoR2) / (IoR1 + IoR2)) * ((IoR1 - IoR2) / (IoR1 + IoR2));
+    return (float)((double)r0 + (double)(1.0f - r0) * pow5_own(1.0 - (double)cosTheta));
+}
+
+struct PathState {
+    vec3 o, d, color;
+};
+
+// scatterRay, src/interactions.h:111-256.  Returns true when the OBJ emissive-texel branch ended the path
+// (the reference sets remainingBounces = 1 there and its caller decrements it to 0).
+PT_DEV bool scatterRay(const DScene &sc, PathState &ps, vec3 intersect, const Hit &hit, const DMaterial &m, Rng &rng) {
+    vec3 n = hit.n;
+    if (m.hasReflective > 0) {
+        vec3 reflectDir = reflect(ps.d, n);
+        float spec = powf_own(fmax_glm(dot(neg(ps.d), reflectDir), 0.0f), m.exponent);
+        ps.color = mul(ps.color, scale(V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]), m.hasReflective * spec));
+        ps.o = add(intersect, scale(n, 0.01f));
+        ps.d = reflectDir;
+    } else if (m.hasRefractive > 0) {
+        float IoR1 = 1.0f;
+        float IoR2 = m.ior;
+        float cosTheta = dot(neg(ps.d), n);
+        if (cosTheta < 0) {
+            n = scale(n, -1.0f);
+            IoR1 = IoR2;
+            IoR2 = 1.0f;
+            cosTheta = __builtin_fabsf(cosTheta);
+        }
+        float sinTheta = (float)__builtin_sqrt(1.0 - (double)(cosTheta * cosTheta));
+        vec3 nd;
+        if (IoR1 / IoR2 * sinTheta > 1.0f) {
+            nd = reflect(ps.d, n);
+        } else {
+            float reflect_coeff = schlick(IoR1, IoR2, cosTheta);
+            float random = rng.uniform(0.f, 1.f);
+            if (random < reflect_coeff) nd = reflect(ps.d, n);
+            else nd = refract(ps.d, n, IoR1 / IoR2);
+        }
+        ps.d = nd;
+        ps.color = mul(ps.color, V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]));
+        ps.o = add(intersect, scale(nd, 0.01f));
+    } else if (sc.geoms[hit.geom].type == G_OBJ) {
+        const DGeom &geom = sc.geoms[hit.geom];
+        const DTex &kd = geom.tex[0], &ks = geom.tex[1], &ke = geom.tex[2];
+        vec3 emission = V3(0.f, 0.f, 0.f);
+        if (ke.ch) {
+            int coordU = (int)(hit.u * ke.w);
+            int coordV = (int)(hit.v * ke.h);
+            int pixelID = coordV * ke.w + coordU;
+            emission = V3(texel(sc, ke, pixelID, 0) / 255.f, texel(sc, ke, pixelID, 1) / 255.f, texel(sc, ke, pixelID, 2) / 255.f);
+        }
+        const float eps = 1.1920928955078125e-07f;
+        if (emission.x > eps || emission.y > eps || emission.z > eps) {
+            ps.color = mul(ps.color, scale(emission, 5.0f));
+            return true;
+        }
+        float cosTheta = dot(neg(ps.d), n);
+        float reflect_coeff = schlick(1.0f, m.ior, cosTheta);
+        float random = rng.uniform(0.f, 1.f);
+        if (random < reflect_coeff) {
+            int coordU = (int)(hit.u * ks.w);
+            int coordV = (int)(hit.v * ks.h);
+            int pixelID = coordV * ks.w + coordU;
+            vec3 reflectDir = reflect(ps.d, n);
+            float spec = 1.0f;      // glm::pow(x, 0.0f) == 1 for every x (src/interactions.h:203)
+            vec3 specColor;
+            if (ks.ch) specColor = V3(texel(sc, ks, pixelID, 0) / 255.f, texel(sc, ks, pixelID, 1) / 255.f, texel(sc, ks, pixelID, 2) / 255.f);
+            else specColor = V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]);
+            specColor = scale(specColor, spec);
+            ps.color = mul(ps.color, specColor);
+            ps.o = add(intersect, scale(n, 0.01f));
+            ps.d = reflectDir;
+        } else {
+            int coordU = (int)(hit.u * kd.w);
+            int coordV = (int)(hit.v * kd.h);
+            int pixelID = coordV * kd.w + coordU;
+            vec3 diffuseColor;
+            if (kd.ch) diffuseColor = V3(texel(sc, kd, pixelID, 0) / 255.f, texel(sc, kd, pixelID, 1) / 255.f, texel(sc, kd, pixelID, 2) / 255.f);
+            else diffuseColor = V3(m.color[0], m.color[1], m.color[2]);
+            ps.color = mul(ps.color, diffuseColor);
+            vec3 nd = randomDirectionInHemisphere(n, rng);
+            ps.d = nd;
+            ps.o = add(intersect, scale(nd, 0.01f));
+        }
+    } else {
+        vec3 nd = randomDirectionInHemisphere(n, rng);
+        ps.d = nd;
+        ps.o = add(intersect, scale(nd, 0.01f));
+        ps.color = mul(ps.color, V3(m.color[0], m.color[1], m.color[2]));
+    }
+    return false;
+}
+
+// ConcentricSampleDisk, src/pathtrace.cu:183-197
+PT_DEV void concentricSampleDisk(float px, float py, float &ox, float &oy) {
+    float ux = 2.f * px - 1.f, uy = 2.f * py - 1.f;
+    if (ux == 0 && uy == 0) { ox = 0; oy = 0; return; }
+    float theta, r;
+    if (__builtin_fabsf(ux) > __builtin_fabsf(uy)) {
+        r = ux;
+        theta = 0.785398f * (uy / ux);
+    } else {
+        r = uy;
+        theta = 1.570796f - 0.785398f * (ux / uy);
+    }
+    float sn, cs;
+    sincos_own(theta, &sn, &cs);
+    ox = r * cs;
+    oy = r * sn;
+}
+
+// body of generateRayFromCamera, src/pathtrace.cu:208-254
+PT_DEV void generateRay(const DCamera &cam, int iter, int traceDepth, bool aa, bool dof, int x, int y, PathState &ps) {
+    int index = x + (y * cam.resx);
+    vec3 origin = V3(cam.position[0], cam.position[1], cam.position[2]);
+    float antia_x = (float)x;
+    float antia_y = (float)y;
+    if (aa) {
+        Rng rngANTIA; rngANTIA.seed(iter, index, traceDepth);
+        antia_x += rngANTIA.uniform(-0.5f, 0.5f);
+        antia_y += rngANTIA.uniform(-0.5f, 0.5f);
+    }
+    vec3 right = V3(cam.right[0], cam.right[1], cam.right[2]);
+    vec3 up = V3(cam.up[0], cam.up[1], cam.up[2]);
+    vec3 view = V3(cam.view[0], cam.view[1], cam.view[2]);
+    vec3 a = scale(scale(right, cam.pixelLength[0]), antia_x - (float)cam.resx * 0.5f);
+    vec3 b = scale(scale(up, cam.pixelLength[1]), antia_y - (float)cam.resy * 0.5f);
+    vec3 direction = normalize(sub(sub(view, a), b));
+    if (dof) {
+        const float lensRadius = 0.8f;
+        const float focalDistance = 11.0f;
+        Rng rng; rng.seed(iter, index, traceDepth);
+        float s0 = rng.uniform(0.f, 1.f);
+        float s1 = rng.uniform(0.f, 1.f);
+        float lx, ly;
+        concentricSampleDisk(s0, s1, lx, ly);
+        lx = lensRadius * lx; ly = lensRadius * ly;
+        float ft = __builtin_fabsf(focalDistance / direction.z);
+        vec3 pFocus = add(origin, scale(direction, ft));
+        origin = add(origin, V3(lx, ly, 0.f));
+        direction = normalize(sub(pFocus, origin));
+    }
+    ps.o = origin;
+    ps.d = direction;
+    ps.color = V3(1.0f, 1.0f, 1.0f);
+}
+
+}  // namespace ptd

@@ -1,0 +1,954 @@
+// pt_engine.hip -- MI355X (gfx950) path-tracing engine behind include/mi355x_pathtracer.h.
+//
+// Replaces the device side of the reference's src/pathtrace.cu.  Design (see DESIGN.md for the full account):
+//
+//  * Streams are SoA (one fp32/int32 array per field, coalesced 256-B wave accesses), not the reference's 44-B
+//    PathSegment / 32-B ShadeableIntersection AoS records.
+//  * One bounce = one fused kernel + one stable multi-bin partition:
+//      k_bounce : shade(b-1) [src/pathtrace.cu:355-404 + interactions.h scatterRay] immediately followed by
+//                 computeIntersections(b) [:261-344] of the scattered ray, for every path still alive; bounce 0
+//                 fuses generateRayFromCamera [:206-255] instead of a shade.  Paths that end at bounce b (miss,
+//                 light, last bounce, emissive texel) add their radiance to the image right there, which is
+//                 what finalGather [:407-416] would do later (each pixel exactly once per iteration), and are
+//                 dropped -- only paths that will scatter again are stored.
+//      k_scan   : exclusive scan of the per-tile per-material counts.
+//      k_move   : writes every stored path to its rank in (material descending, previous order) order.  That
+//                 single stable counting sort equals the reference's stable_partition [:541] followed by the
+//                 next bounce's stable sort_by_key by material [:518].  The rank a path WOULD have among all
+//                 survivors (including the ones that were dropped) is carried as its stream index, because
+//                 that index seeds the shading RNG [:373] and must be the reference's.
+//  * The live count never visits the host: kernels read it from device memory and use grid-stride tile loops,
+//    so an iteration is a fixed sequence of launches on one stream.
+//  * Scene data (<= a few KB) is read with wave-uniform indices, i.e. through the scalar cache into SGPRs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/mi355x_pathtracer.h"
+#include "pt_device.h"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_last_error;
+int set_error(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr int TILE = 256;          // paths per tile = threads per workgroup (4 waves of 64)
+constexpr int WAVES = TILE / 64;
+
+// SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
+// k_bounce in tile order before k_move sorts it.
+struct PathSoA {
+    float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb;   // ray + throughput colour
+    float *t, *nx, *ny, *nz, *u, *v;                     // pending intersection
+    int32_t *pix;                                        // pixelIndex (global, x + y*W)
+    int32_t *mg;                                         // materialId | geomId << 16
+    int32_t *idx;                                        // stream: RNG stream index; stage: bin or -1
+    int32_t *rank;                                       // stage only: rank among all | rank among stored << 16
+};
+constexpr int SOA_FLOATS = 15, SOA_INTS = 4;
+
+struct TileMap {           // which pixels this device owns (row blocks round-robin over tile_world)
+    int32_t W, H, tile_rows, tile_rank, tile_world, owned;
+};
+
+__device__ __forceinline__ void owned_pixel(const TileMap &tm, int i, int &x, int &y) {
+    int r = i / tm.W;
+    x = i - r * tm.W;
+    if (tm.tile_world <= 1) { y = r; return; }
+    int k = r / tm.tile_rows;
+    y = (k * tm.tile_world + tm.tile_rank) * tm.tile_rows + (r - k * tm.tile_rows);
+}
+
+struct BounceParams {
+    DScene sc;
+    DCamera cam;
+    TileMap tm;
+    PathSoA in, stage;
+    float *image;
+    int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
+    int32_t aa, dof, sort;
+    int32_t nbins, maxTiles;
+    const int32_t *totals_prev;            // [nbins] stored-path totals of bounce b-1 (n_in = their sum)
+    int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]
+    // first-bounce cache fill (iter 1, AA and DoF off): bounce-0 light hits are replayed on later iterations
+    int32_t *emit_count; int32_t *emit_pix; float *emit_rgb;
+};
+
+__device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
+    int s = 0;
+    for (int b = 0; b < n; b++) s += t[b];
+    return s;
+}
+
+// One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
+template <bool FIRST>
+__global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];     // [2][WAVES][nbins]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = p.nbins;
+    int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
+    const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev, nb);
+    const int ntiles = (n_in + TILE - 1) / TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * TILE + tid;
+        bool alive = i < n_in;
+        PathState ps;
+        int pix = 0;
+        ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
+        if (alive) {
+            if (FIRST) {
+                int x, y;
+                owned_pixel(p.tm, i, x, y);
+                pix = x + y * p.cam.resx;
+                generateRay(p.cam, p.iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
+            } else {
+                // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
+                ps.o = V3(p.in.ox[i], p.in.oy[i], p.in.oz[i]);
+                ps.d = V3(p.in.dx[i], p.in.dy[i], p.in.dz[i]);
+                ps.color = V3(p.in.cr[i], p.in.cg[i], p.in.cb[i]);
+                pix = p.in.pix[i];
+                Hit h;
+                h.t = p.in.t[i];
+                h.n = V3(p.in.nx[i], p.in.ny[i], p.in.nz[i]);
+                h.u = p.in.u[i]; h.v = p.in.v[i];
+                int mg = p.in.mg[i];
+                h.mat = mg & 0xffff; h.geom = mg >> 16;
+                Rng rng; rng.seed(p.iter, p.in.idx[i], 0);
+                vec3 intersect = add(ps.o, scale(ps.d, h.t));
+                bool ended = scatterRay(p.sc, ps, intersect, h, p.sc.mats[h.mat], rng);
+                if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
+                    float *px = p.image + (size_t)pix * 3;
+                    px[0] += ps.color.x; px[1] += ps.color.y; px[2] += ps.color.z;
+                    alive = false;
+                }
+            }
+        }
+        // computeIntersections(b) + the terminal cases of shadeFakeMaterial(b)
+        int bin = -1;
+        bool pending = false;
+        Hit hit;
+        hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
+        if (alive) {
+            Ray ray; ray.o = ps.o; ray.d = ps.d;
+            intersectScene(p.sc, ray, hit);
+            bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
+            if (hit.t > 0.0f) {
+                const DMaterial &m = p.sc.mats[hit.mat];
+                if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
+                    vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
+                    float *px = p.image + (size_t)pix * 3;
+                    px[0] += c.x; px[1] += c.y; px[2] += c.z;
+                    if (FIRST && p.emit_count) {
+                        int k = atomicAdd(p.emit_count, 1);
+                        p.emit_pix[k] = pix;
+                        p.emit_rgb[k * 3 + 0] = c.x; p.emit_rgb[k * 3 + 1] = c.y; p.emit_rgb[k * 3 + 2] = c.z;
+                    }
+                } else if (p.traceDepth - p.bounce != 1) {         // :387-390 (last bounce => black)
+                    pending = true;
+                }
+            }
+        }
+        // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
+        // index) and among the stored ones (-> storage position)
+        for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
+        __syncthreads();
+        int r_all = 0, r_scat = 0;
+        {
+            unsigned long long remaining = __ballot(alive);
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            while (remaining) {
+                int leader = __ffsll((long long)remaining) - 1;
+                int b = __shfl(bin, leader);
+                unsigned long long m_all = __ballot(alive && bin == b);
+                unsigned long long m_scat = __ballot(pending && bin == b);
+                if (alive && bin == b) {
+                    r_all = __popcll(m_all & lt);
+                    r_scat = __popcll(m_scat & lt);
+                }
+                if (lane == leader) {
+                    w_all[wave * nb + b] = __popcll(m_all);
+                    w_scat[wave * nb + b] = __popcll(m_scat);
+                }
+                remaining &= ~m_all;
+            }
+        }
+        __syncthreads();
+        if (alive) {
+            for (int w = 0; w < wave; w++) { r_all += w_all[w * nb + bin]; r_scat += w_scat[w * nb + bin]; }
+        }
+        for (int b = tid; b < nb; b += TILE) {
+            int ca = 0, cs = 0;
+            for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
+            p.counts_all[(size_t)b * p.maxTiles + tile] = ca;
+            p.counts_scat[(size_t)b * p.maxTiles + tile] = cs;
+        }
+        if (i < n_in) {
+            p.stage.idx[i] = pending ? bin : -1;
+            if (pending) {
+                p.stage.rank[i] = r_all | (r_scat << 16);
+                p.stage.ox[i] = ps.o.x; p.stage.oy[i] = ps.o.y; p.stage.oz[i] = ps.o.z;
+                p.stage.dx[i] = ps.d.x; p.stage.dy[i] = ps.d.y; p.stage.dz[i] = ps.d.z;
+                p.stage.cr[i] = ps.color.x; p.stage.cg[i] = ps.color.y; p.stage.cb[i] = ps.color.z;
+                p.stage.t[i] = hit.t;
+                p.stage.nx[i] = hit.n.x; p.stage.ny[i] = hit.n.y; p.stage.nz[i] = hit.n.z;
+                p.stage.u[i] = hit.u; p.stage.v[i] = hit.v;
+                p.stage.pix[i] = pix;
+                p.stage.mg[i] = hit.mat | (hit.geom << 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct ScanParams {
+    int32_t nbins, maxTiles, first, owned;
+    const int32_t *totals_prev;
+    int32_t *counts_all, *counts_scat;
+    int32_t *totals_all, *totals_scat;     // [nbins] of this bounce
+};
+
+// Exclusive scan along tiles of one (which, bin) column; grid = (nbins, 2), 1024 threads.
+__global__ __launch_bounds__(1024) void k_scan(const ScanParams p) {
+    __shared__ int32_t part[1024];
+    const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev, p.nbins);
+    const int ntiles = (n_in + TILE - 1) / TILE;
+    int32_t *col = (which ? p.counts_scat : p.counts_all) + (size_t)b * p.maxTiles;
+    const int chunk = (ntiles + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, ntiles);
+    int s = 0;
+    for (int k = lo; k < hi; k++) s += col[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of 1024 partials
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int k = lo; k < hi; k++) { int c = col[k]; col[k] = run; run += c; }
+    if (tid == 1023) (which ? p.totals_scat : p.totals_all)[b] = part[1023];
+}
+
+struct MoveParams {
+    PathSoA stage, out;
+    int32_t nbins, maxTiles, first, owned;
+    const int32_t *totals_prev;
+    const int32_t *counts_all, *counts_scat, *totals_all, *totals_scat;
+};
+
+// Stable multi-bin partition: stored path -> position base_scat[bin] + tile prefix + in-tile rank.
+__global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];     // base_all[nb], base_scat[nb]
+    const int nb = p.nbins, tid = threadIdx.x;
+    int32_t *base_all = lds, *base_scat = lds + nb;
+    if (tid == 0) {
+        int a = 0, s = 0;
+        for (int b = 0; b < nb; b++) { base_all[b] = a; base_scat[b] = s; a += p.totals_all[b]; s += p.totals_scat[b]; }
+    }
+    __syncthreads();
+    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev, nb);
+    const int ntiles = (n_in + TILE - 1) / TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * TILE + tid;
+        if (i >= n_in) continue;
+        const int bin = p.stage.idx[i];
+        if (bin < 0) continue;
+        const int r = p.stage.rank[i];
+        const int idx = base_all[bin] + p.counts_all[(size_t)bin * p.maxTiles + tile] + (r & 0xffff);
+        const int pos = base_scat[bin] + p.counts_scat[(size_t)bin * p.maxTiles + tile] + (r >> 16);
+        p.out.ox[pos] = p.stage.ox[i]; p.out.oy[pos] = p.stage.oy[i]; p.out.oz[pos] = p.stage.oz[i];
+        p.out.dx[pos] = p.stage.dx[i]; p.out.dy[pos] = p.stage.dy[i]; p.out.dz[pos] = p.stage.dz[i];
+        p.out.cr[pos] = p.stage.cr[i]; p.out.cg[pos] = p.stage.cg[i]; p.out.cb[pos] = p.stage.cb[i];
+        p.out.t[pos] = p.stage.t[i];
+        p.out.nx[pos] = p.stage.nx[i]; p.out.ny[pos] = p.stage.ny[i]; p.out.nz[pos] = p.stage.nz[i];
+        p.out.u[pos] = p.stage.u[i]; p.out.v[pos] = p.stage.v[i];
+        p.out.pix[pos] = p.stage.pix[i];
+        p.out.mg[pos] = p.stage.mg[i];
+        p.out.idx[pos] = idx;
+    }
+}
+
+// replay of the cached bounce-0 light hits (first-bounce cache, iterations > 1)
+__global__ void k_replay_emission(const int32_t *count, const int32_t *pix, const float *rgb, float *image) {
+    int n = *count;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        float *px = image + (size_t)pix[k] * 3;
+        px[0] += rgb[k * 3 + 0]; px[1] += rgb[k * 3 + 1]; px[2] += rgb[k * 3 + 2];
+    }
+}
+
+// per-iteration statistics: rays entering the intersect stage of each bounce = sum of totals_all[bounce]
+// (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced)
+__global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int64_t *last, int64_t *total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t sum = 0;
+        for (int b = 0; b < nbounces; b++) {
+            int64_t s = 0;
+            if (!(b == 0 && skip_first))
+                for (int k = 0; k < nbins; k++) s += totals[(size_t)b * stride + k];
+            if (b < 64) last[b] = s;
+            sum += s;
+        }
+        *total += sum;
+    }
+}
+
+// sendImageToPBO, src/pathtrace.cu:69-89
+__global__ void k_pbo(uchar4 *pbo, int n, int iter, const float *image) {
+    int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index < n) {
+        const float *pix = image + (size_t)index * 3;
+        int c[3];
+        for (int k = 0; k < 3; k++) {
+            int v = (int)(pix[k] / (float)iter * 255.0);
+            c[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        uchar4 o; o.w = 0; o.x = (unsigned char)c[0]; o.y = (unsigned char)c[1]; o.z = (unsigned char)c[2];
+        pbo[index] = o;
+    }
+}
+
+// ---- per-stage kernels for the parity tests (AoS records of the reference in, same out) ----------------------
+struct HostPath { float o[3], d[3], c[3]; int32_t pixelIndex, remainingBounces; };       // 44 B
+struct HostIsect { float t, n[3]; int32_t materialId; float uv[2]; int32_t geomId; };    // 32 B
+
+__global__ void k_kat_geom(DScene sc, int gi, int n, const float *rays, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DGeom &g = sc.geoms[gi];
+    Ray r; r.o = ld3(rays + i * 6); r.d = ld3(rays + i * 6 + 3);
+    vec3 p = V3(0, 0, 0), nrm = V3(0, 0, 0);
+    float u = 0.f, v = 0.f;
+    bool outside = true;
+    float t = -1.f;
+    if (g.type == G_CUBE) t = boxIntersectionTest(g, r, p, nrm, outside);
+    else if (g.type == G_SPHERE) t = sphereIntersectionTest(g, r, p, nrm, outside);
+    else if (g.type == G_OBJ) t = meshIntersectionTest(sc, g, r, p, nrm, u, v, outside);
+    float *o = out + i * 10;
+    o[0] = t; o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = nrm.x; o[5] = nrm.y; o[6] = nrm.z; o[7] = u; o[8] = v;
+    o[9] = outside ? 1.f : 0.f;
+}
+
+__global__ void k_kat_intersect(DScene sc, int n, const HostPath *paths, HostIsect *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; r.o = ld3(paths[i].o); r.d = ld3(paths[i].d);
+    Hit h;
+    intersectScene(sc, r, h);
+    HostIsect o;
+    memset(&o, 0, sizeof o);
+    if (h.t > 0.f) {
+        o.t = h.t; o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z; o.materialId = h.mat; o.uv[0] = h.u; o.uv[1] = h.v;
+        o.geomId = h.geom;
+    } else {
+        o.t = -1.f;
+    }
+    out[i] = o;
+}
+
+// shadeFakeMaterial in full (src/pathtrace.cu:365-403), one path per thread, idx[] = RNG stream indices
+__global__ void k_kat_shade(DScene sc, int iter, int n, const int32_t *idx, const HostIsect *isects, HostPath *paths) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    HostIsect is = isects[i];
+    HostPath seg = paths[i];
+    if (is.t > 0.0f) {
+        const DMaterial &m = sc.mats[is.materialId];
+        if (m.emittance > 0.0f) {
+            vec3 c = mul(ld3(seg.c), scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
+            seg.c[0] = c.x; seg.c[1] = c.y; seg.c[2] = c.z;
+            seg.remainingBounces = 0;
+        } else if (seg.remainingBounces == 1) {
+            seg.c[0] = seg.c[1] = seg.c[2] = 0.f;
+            seg.remainingBounces = 0;
+        } else {
+            PathState ps; ps.o = ld3(seg.o); ps.d = ld3(seg.d); ps.color = ld3(seg.c);
+            Hit h; h.t = is.t; h.n = ld3(is.n); h.u = is.uv[0]; h.v = is.uv[1]; h.mat = is.materialId; h.geom = is.geomId;
+            Rng rng; rng.seed(iter, idx[i], 0);
+            vec3 intersect = add(ps.o, scale(ps.d, h.t));
+            bool ended = scatterRay(sc, ps, intersect, h, m, rng);
+            seg.o[0] = ps.o.x; seg.o[1] = ps.o.y; seg.o[2] = ps.o.z;
+            seg.d[0] = ps.d.x; seg.d[1] = ps.d.y; seg.d[2] = ps.d.z;
+            seg.c[0] = ps.color.x; seg.c[1] = ps.color.y; seg.c[2] = ps.color.z;
+            if (ended) seg.remainingBounces = 1;
+            seg.remainingBounces -= 1;
+        }
+    } else {
+        seg.c[0] = seg.c[1] = seg.c[2] = 0.f;
+        seg.remainingBounces = 0;
+    }
+    paths[i] = seg;
+}
+
+__global__ void k_kat_generate(DCamera cam, int iter, int traceDepth, int aa, int dof, HostPath *paths) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = cam.resx * cam.resy;
+    if (i >= n) return;
+    int y = i / cam.resx, x = i - y * cam.resx;
+    PathState ps;
+    generateRay(cam, iter, traceDepth, aa != 0, dof != 0, x, y, ps);
+    HostPath seg;
+    seg.o[0] = ps.o.x; seg.o[1] = ps.o.y; seg.o[2] = ps.o.z;
+    seg.d[0] = ps.d.x; seg.d[1] = ps.d.y; seg.d[2] = ps.d.z;
+    seg.c[0] = ps.color.x; seg.c[1] = ps.color.y; seg.c[2] = ps.color.z;
+    seg.pixelIndex = i; seg.remainingBounces = traceDepth;
+    paths[i] = seg;
+}
+
+__global__ void k_kat_libm(int n, const float *x, float *s, float *c, const double *pw, double *p5,
+                           const float *pxy, float *pout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    sincos_own(x[i], &sn, &cs);
+    s[i] = sn; c[i] = cs;
+    p5[i] = pow5_own(pw[i]);
+    pout[i] = powf_own(pxy[2 * i], pxy[2 * i + 1]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+struct ptx_tracer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timing_valid = false;
+    ptx_options opt{};
+    DCamera cam{};
+    int traceDepth = 0;
+    TileMap tm{};
+    int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, cap = 0;
+    // device memory
+    DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
+    float *d_image = nullptr; bool own_image = false;
+    float *d_fbuf[3] = {nullptr, nullptr, nullptr};      // stream, stage, cache
+    int32_t *d_ibuf[3] = {nullptr, nullptr, nullptr};
+    PathSoA soa[3];                                      // 0 = stream, 1 = stage, 2 = first-bounce cache
+    int32_t *d_counts = nullptr;                         // [2][nbins][maxTiles]
+    int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins]
+    int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
+    int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
+    int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total
+    int maxBounces = 0;
+    bool cache_valid = false;
+    int64_t iterations = 0;
+    double loop_ms_total = 0.0;
+    // debug capture
+    int capture_bounce = -1;
+    int32_t *d_cap = nullptr;                            // pix, idx, mg [cap each] + totals
+    float *d_cap_f = nullptr;                            // the 15 float fields [cap each]
+    bool cap_filled = false;
+    DScene scene() const {
+        DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
+        return s;
+    }
+    bool cache_active() const { return opt.cache_first_bounce && !opt.antialiasing && !opt.depth_of_field; }
+};
+
+namespace {
+
+void carve(PathSoA &s, float *f, int32_t *i, size_t cap) {
+    float **fp[SOA_FLOATS] = {&s.ox, &s.oy, &s.oz, &s.dx, &s.dy, &s.dz, &s.cr, &s.cg, &s.cb, &s.t, &s.nx, &s.ny, &s.nz, &s.u, &s.v};
+    for (int k = 0; k < SOA_FLOATS; k++) *fp[k] = f + (size_t)k * cap;
+    s.pix = i; s.mg = i + cap; s.idx = i + 2 * cap; s.rank = i + 3 * cap;
+}
+
+void camera_to_device(const ptx_camera &c, DCamera &d) {
+    d.resx = c.resolution[0]; d.resy = c.resolution[1];
+    memcpy(d.position, c.position, 12); memcpy(d.lookAt, c.lookAt, 12); memcpy(d.view, c.view, 12);
+    memcpy(d.up, c.up, 12); memcpy(d.right, c.right, 12); memcpy(d.fov, c.fov, 8); memcpy(d.pixelLength, c.pixelLength, 8);
+}
+
+int free_tracer(ptx_tracer *t) {
+    if (!t) return PTX_OK;
+    hipSetDevice(t->device);
+    if (t->stream) hipStreamSynchronize(t->stream);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_texels);
+    if (t->own_image) hipFree(t->d_image);
+    for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
+    hipFree(t->d_counts); hipFree(t->d_totals); hipFree(t->d_cache_totals);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f);
+    if (t->ev_start) hipEventDestroy(t->ev_start);
+    if (t->ev_stop) hipEventDestroy(t->ev_stop);
+    if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
+    delete t;
+    return PTX_OK;
+}
+
+int enqueue_iteration(ptx_tracer *t, int iter) {
+    const int nb = t->nbins;
+    const size_t lds_bounce = sizeof(int32_t) * 2 * WAVES * nb;
+    const size_t lds_move = sizeof(int32_t) * 2 * nb;
+    const bool cache_on = t->cache_active();
+    const bool use_cache = cache_on && t->cache_valid && iter != 1;
+    const bool fill_cache = cache_on && !use_cache;
+    int32_t *counts_all = t->d_counts, *counts_scat = t->d_counts + (size_t)nb * t->maxTiles;
+    auto totals = [&](int bounce, int which) { return t->d_totals + ((size_t)bounce * 2 + which) * nb; };
+
+    if (fill_cache) HIPCHECK(hipMemsetAsync(t->d_emit_count, 0, sizeof(int32_t), t->stream));
+    for (int b = 0; b < t->traceDepth; b++) {
+        const bool first = b == 0;
+        if (first && use_cache) {
+            // first-bounce cache: the sorted bounce-0 stream and its light hits are identical every iteration
+            // when primary rays are not jittered, so bounce 0 is skipped (intent of src/pathtrace.cu:492-499,514)
+            HIPCHECK(hipMemcpyAsync(totals(0, 0), t->d_cache_totals, sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, t->stream));
+            hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, t->stream, t->d_emit_count, t->d_emit_pix,
+                               t->d_emit_rgb, t->d_image);
+            continue;
+        }
+        BounceParams bp;
+        bp.sc = t->scene(); bp.cam = t->cam; bp.tm = t->tm;
+        bp.in = (b == 1 && cache_on) ? t->soa[2] : t->soa[0];   // with the cache on, bounce 0 always lands in soa[2]
+        bp.stage = t->soa[1];
+        bp.image = t->d_image;
+        bp.iter = iter; bp.traceDepth = t->traceDepth; bp.bounce = b;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material;
+        bp.nbins = nb; bp.maxTiles = t->maxTiles;
+        bp.totals_prev = first ? nullptr : totals(b - 1, 1);
+        bp.counts_all = counts_all; bp.counts_scat = counts_scat;
+        bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
+        bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
+        if (first) hipLaunchKernelGGL(k_bounce<true>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp);
+        else hipLaunchKernelGGL(k_bounce<false>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp);
+
+        ScanParams sp;
+        sp.nbins = nb; sp.maxTiles = t->maxTiles; sp.first = first; sp.owned = t->tm.owned;
+        sp.totals_prev = bp.totals_prev;
+        sp.counts_all = counts_all; sp.counts_scat = counts_scat;
+        sp.totals_all = totals(b, 0); sp.totals_scat = totals(b, 1);
+        hipLaunchKernelGGL(k_scan, dim3(nb, 2), dim3(1024), 0, t->stream, sp);
+
+        if (b + 1 < t->traceDepth) {
+            MoveParams mp;
+            mp.stage = t->soa[1];
+            mp.out = (first && cache_on) ? t->soa[2] : t->soa[0];
+            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned;
+            mp.totals_prev = bp.totals_prev;
+            mp.counts_all = counts_all; mp.counts_scat = counts_scat;
+            mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
+            hipLaunchKernelGGL(k_move, dim3(t->grid), dim3(TILE), lds_move, t->stream, mp);
+        }
+        if (first && fill_cache) {
+            HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, t->stream));
+            t->cache_valid = true;
+        }
+        if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {
+            const PathSoA &src = (first && cache_on) ? t->soa[2] : t->soa[0];
+            size_t cb = sizeof(int32_t) * (size_t)t->cap;
+            HIPCHECK(hipMemcpyAsync(t->d_cap, src.pix, cb, hipMemcpyDeviceToDevice, t->stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx, cb, hipMemcpyDeviceToDevice, t->stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg, cb, hipMemcpyDeviceToDevice, t->stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, t->stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap_f, src.ox, sizeof(float) * SOA_FLOATS * (size_t)t->cap, hipMemcpyDeviceToDevice, t->stream));
+            t->cap_filled = true;
+        }
+    }
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, t->d_stats,
+                       t->d_stats + 64);
+    HIPCHECK(hipGetLastError());
+    t->iterations++;
+    return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ptx_last_error(void) { return g_last_error.c_str(); }
+void ptx_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }
+
+int ptx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void ptx_default_options(ptx_options *o) {
+    memset(o, 0, sizeof *o);
+    o->depth_of_field = 0; o->cache_first_bounce = 1; o->sort_by_material = 1; o->antialiasing = 1; o->bounding_box = 0;
+    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1;
+}
+
+int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
+               const ptx_camera *camera, int trace_depth, const ptx_options *options, float *external_image,
+               void *stream, ptx_tracer **out) {
+    if (!out) return set_error(PTX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (ngeoms < 0 || nmaterials < 0 || (ngeoms && !geoms) || (nmaterials && !materials) || !camera)
+        return set_error(PTX_ERR_INVALID, "missing scene arrays");
+    if (camera->resolution[0] <= 0 || camera->resolution[1] <= 0) return set_error(PTX_ERR_INVALID, "resolution must be positive");
+    if (trace_depth < 1) return set_error(PTX_ERR_UNSUPPORTED, "trace depth must be >= 1");
+    if (nmaterials > 65535 || ngeoms > 32767) return set_error(PTX_ERR_UNSUPPORTED, "more than 65535 materials or 32767 geoms");
+    ptx_options opt;
+    if (options) opt = *options; else ptx_default_options(&opt);
+    if (opt.bounding_box) return set_error(PTX_ERR_UNSUPPORTED, "BOUNDING_BOX culling is off in the reference and not implemented");
+    if (opt.tile_world < 1) opt.tile_world = 1;
+    if (opt.tile_world > 1 && (opt.tile_rows < 1 || opt.tile_rank < 0 || opt.tile_rank >= opt.tile_world))
+        return set_error(PTX_ERR_INVALID, "bad tile split");
+    for (int i = 0; i < ngeoms; i++) {
+        if (geoms[i].materialid < 0 || geoms[i].materialid >= nmaterials)
+            return set_error(PTX_ERR_INVALID, "geom " + std::to_string(i) + " refers to a material that does not exist");
+        if (geoms[i].faceSize < 0 || (geoms[i].faceSize > 0 && !geoms[i].faces)) return set_error(PTX_ERR_INVALID, "bad face array");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return set_error(PTX_ERR_NODEVICE, "no HIP device available; this library has no CPU path");
+    int dev = opt.device;
+    if (dev < 0) HIPCHECK(hipGetDevice(&dev));
+    if (dev >= ndev) return set_error(PTX_ERR_INVALID, "device ordinal out of range");
+    HIPCHECK(hipSetDevice(dev));
+
+    ptx_tracer *t = new ptx_tracer;
+    t->device = dev; t->opt = opt; t->traceDepth = trace_depth; t->ngeoms = ngeoms; t->nmats = nmaterials;
+    camera_to_device(*camera, t->cam);
+    const int W = t->cam.resx, H = t->cam.resy;
+    // tile split: rows owned by this device
+    t->tm.W = W; t->tm.H = H; t->tm.tile_world = opt.tile_world; t->tm.tile_rank = opt.tile_rank;
+    t->tm.tile_rows = opt.tile_world > 1 ? opt.tile_rows : H;
+    int owned_rows = 0;
+    if (opt.tile_world <= 1) owned_rows = H;
+    else for (int y = 0; y < H; y++) if ((y / opt.tile_rows) % opt.tile_world == opt.tile_rank) owned_rows++;
+    t->tm.owned = owned_rows * W;
+    t->cap = t->tm.owned > 0 ? t->tm.owned : 1;
+    t->maxTiles = (t->cap + TILE - 1) / TILE;
+    t->nbins = opt.sort_by_material ? (nmaterials > 0 ? nmaterials : 1) : 1;
+    t->maxBounces = trace_depth;
+    hipDeviceProp_t prop;
+    auto fail = [&](int code) { free_tracer(t); return code; };
+#define HC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(PTX_ERR_HIP); } } while (0)
+    HC(hipGetDeviceProperties(&prop, dev));
+    t->grid = std::min(t->maxTiles, prop.multiProcessorCount * 8);
+    if (t->grid < 1) t->grid = 1;
+    if (stream) { t->stream = (hipStream_t)stream; t->own_stream = false; }
+    else { HC(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)); t->own_stream = true; }
+    HC(hipEventCreate(&t->ev_start)); HC(hipEventCreate(&t->ev_stop));
+
+    // scene upload (pathtraceInit, src/pathtrace.cu:111-146) -- flattened, no host struct is mutated
+    std::vector<DGeom> hg((size_t)std::max(ngeoms, 1));
+    std::vector<float> hfaces;
+    std::vector<uint8_t> htex;
+    for (int i = 0; i < ngeoms; i++) {
+        const ptx_geom &g = geoms[i];
+        DGeom &d = hg[i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.xf, g.transform, 64); memcpy(d.inv, g.inverseTransform, 64); memcpy(d.invT, g.invTranspose, 64);
+        d.type = g.type; d.materialid = g.materialid;
+        d.faceStart = (int32_t)(hfaces.size() / 15); d.faceCount = g.faceSize;
+        if (g.faceSize) hfaces.insert(hfaces.end(), g.faces, g.faces + (size_t)g.faceSize * 15);
+        const ptx_texture *tx[4] = {&g.kd, &g.ks, &g.ke, &g.bump};
+        for (int k = 0; k < 4; k++) {
+            DTex &dt = d.tex[k];
+            if (tx[k]->channels > 0 && tx[k]->image && tx[k]->width > 0 && tx[k]->height > 0) {
+                if (tx[k]->channels < 3) { set_error(PTX_ERR_UNSUPPORTED, "textures need >= 3 channels"); return fail(PTX_ERR_UNSUPPORTED); }
+                dt.w = tx[k]->width; dt.h = tx[k]->height; dt.ch = tx[k]->channels; dt.off = htex.size();
+                size_t nbytes = (size_t)dt.w * dt.h * dt.ch;
+                htex.insert(htex.end(), tx[k]->image, tx[k]->image + nbytes);
+            }
+        }
+    }
+    if (hfaces.empty()) hfaces.resize(15, 0.f);
+    if (htex.empty()) htex.resize(16, 0);
+    std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
+    static_assert(sizeof(DMaterial) == sizeof(ptx_material), "material layout");
+    if (nmaterials) memcpy(hm.data(), materials, sizeof(DMaterial) * (size_t)nmaterials);
+    HC(hipMalloc(&t->d_geoms, sizeof(DGeom) * hg.size()));
+    HC(hipMemcpy(t->d_geoms, hg.data(), sizeof(DGeom) * hg.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_mats, sizeof(DMaterial) * hm.size()));
+    HC(hipMemcpy(t->d_mats, hm.data(), sizeof(DMaterial) * hm.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_faces, sizeof(float) * hfaces.size()));
+    HC(hipMemcpy(t->d_faces, hfaces.data(), sizeof(float) * hfaces.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_texels, htex.size()));
+    HC(hipMemcpy(t->d_texels, htex.data(), htex.size(), hipMemcpyHostToDevice));
+
+    const size_t npix = (size_t)W * H;
+    if (external_image) { t->d_image = external_image; t->own_image = false; }
+    else {
+        HC(hipMalloc(&t->d_image, sizeof(float) * 3 * npix));
+        HC(hipMemset(t->d_image, 0, sizeof(float) * 3 * npix));
+        t->own_image = true;
+    }
+    const int nsoa = t->cache_active() ? 3 : 2;
+    for (int k = 0; k < nsoa; k++) {
+        HC(hipMalloc(&t->d_fbuf[k], sizeof(float) * SOA_FLOATS * (size_t)t->cap));
+        HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * (size_t)t->cap));
+        carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], (size_t)t->cap);
+    }
+    HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles));
+    HC(hipMalloc(&t->d_totals, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces));
+    HC(hipMemset(t->d_totals, 0, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces));
+    HC(hipMalloc(&t->d_cache_totals, sizeof(int32_t) * 2 * (size_t)t->nbins));
+    HC(hipMalloc(&t->d_emit_count, sizeof(int32_t)));
+    HC(hipMemset(t->d_emit_count, 0, sizeof(int32_t)));
+    HC(hipMalloc(&t->d_emit_pix, sizeof(int32_t) * (size_t)t->cap));
+    HC(hipMalloc(&t->d_emit_rgb, sizeof(float) * 3 * (size_t)t->cap));
+    HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 65));
+    HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 65));
+#undef HC
+    *out = t;
+    return PTX_OK;
+}
+
+int ptx_create_from_scene(const ptx_scene *s, const ptx_options *options, float *external_image, void *stream, ptx_tracer **out) {
+    if (!s) return set_error(PTX_ERR_INVALID, "null scene");
+    return ptx_create(ptx_scene_num_geoms(s), ptx_scene_geoms(s), ptx_scene_num_materials(s), ptx_scene_materials(s),
+                      ptx_scene_camera(const_cast<ptx_scene *>(s)), ptx_scene_trace_depth(s), options, external_image, stream, out);
+}
+
+void ptx_destroy(ptx_tracer *t) { free_tracer(t); }
+
+int ptx_set_camera(ptx_tracer *t, const ptx_camera *camera, int trace_depth) {
+    if (!t || !camera) return set_error(PTX_ERR_INVALID, "null argument");
+    if (camera->resolution[0] != t->cam.resx || camera->resolution[1] != t->cam.resy)
+        return set_error(PTX_ERR_INVALID, "resolution is fixed at create (buffer sizes, src/pathtrace.cu:104-109)");
+    if (trace_depth < 1 || trace_depth > t->maxBounces) return set_error(PTX_ERR_INVALID, "trace depth exceeds the depth given at create");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    camera_to_device(*camera, t->cam);
+    t->traceDepth = trace_depth;
+    t->cache_valid = false;
+    return PTX_OK;
+}
+
+int ptx_reset_image(ptx_tracer *t) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipMemsetAsync(t->d_image, 0, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, t->stream));
+    HIPCHECK(hipMemsetAsync(t->d_stats, 0, sizeof(int64_t) * 65, t->stream));
+    t->iterations = 0; t->loop_ms_total = 0.0; t->cache_valid = false;
+    return PTX_OK;
+}
+
+int ptx_render(ptx_tracer *t, int iter_first, int count) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    if (count <= 0) return PTX_OK;
+    HIPCHECK(hipSetDevice(t->device));
+    if (t->timing_valid) {          // fold the previous batch's time into the running total before reusing events
+        float ms = 0.f;
+        HIPCHECK(hipEventSynchronize(t->ev_stop));
+        HIPCHECK(hipEventElapsedTime(&ms, t->ev_start, t->ev_stop));
+        t->loop_ms_total += ms;
+        t->timing_valid = false;
+    }
+    HIPCHECK(hipEventRecord(t->ev_start, t->stream));
+    for (int k = 0; k < count; k++) {
+        int rc = enqueue_iteration(t, iter_first + k);
+        if (rc != PTX_OK) return rc;
+    }
+    HIPCHECK(hipEventRecord(t->ev_stop, t->stream));
+    t->timing_valid = true;
+    return PTX_OK;
+}
+
+int ptx_iterate(ptx_tracer *t, int iter) { return ptx_render(t, iter, 1); }
+
+int ptx_synchronize(ptx_tracer *t) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    return PTX_OK;
+}
+
+int ptx_read_image(ptx_tracer *t, float *host_rgb) {
+    if (!t || !host_rgb) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipMemcpyAsync(host_rgb, t->d_image, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, hipMemcpyDeviceToHost, t->stream));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    return PTX_OK;
+}
+
+float *ptx_device_image(ptx_tracer *t) { return t ? t->d_image : nullptr; }
+void *ptx_stream(ptx_tracer *t) { return t ? (void *)t->stream : nullptr; }
+int ptx_owned_pixels(const ptx_tracer *t) { return t ? t->tm.owned : 0; }
+
+int ptx_write_pbo_device(ptx_tracer *t, int iter, void *device_uchar4) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    if (!device_uchar4) return PTX_OK;                    // NULL pbo => skip (the reference would fault)
+    HIPCHECK(hipSetDevice(t->device));
+    int n = t->cam.resx * t->cam.resy;
+    hipLaunchKernelGGL(k_pbo, dim3((n + 255) / 256), dim3(256), 0, t->stream, (uchar4 *)device_uchar4, n, iter, t->d_image);
+    HIPCHECK(hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba) {
+    if (!t || !host_rgba) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    size_t n = (size_t)t->cam.resx * t->cam.resy;
+    uchar4 *d = nullptr;
+    HIPCHECK(hipMalloc(&d, n * 4));
+    int rc = ptx_write_pbo_device(t, iter, d);
+    if (rc == PTX_OK) {
+        hipError_t e = hipMemcpyAsync(host_rgba, d, n * 4, hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) rc = set_error(PTX_ERR_HIP, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+double ptx_last_loop_ms(ptx_tracer *t) {
+    if (!t || !t->timing_valid) return 0.0;
+    hipSetDevice(t->device);
+    float ms = 0.f;
+    if (hipEventSynchronize(t->ev_stop) != hipSuccess) return 0.0;
+    if (hipEventElapsedTime(&ms, t->ev_start, t->ev_stop) != hipSuccess) return 0.0;
+    return (double)ms;
+}
+
+int ptx_get_stats(ptx_tracer *t, ptx_stats *out) {
+    if (!t || !out) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    int64_t h[65];
+    HIPCHECK(hipMemcpy(h, t->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->bounces = t->traceDepth;
+    for (int b = 0; b < 64 && b < t->traceDepth; b++) out->rays_per_bounce[b] = h[b];
+    out->rays_total = h[64];
+    out->loop_ms_total = t->loop_ms_total + ptx_last_loop_ms(t);
+    out->iterations = t->iterations;
+    return PTX_OK;
+}
+
+// ---- per-stage entry points -----------------------------------------------------------------------------------
+#define KAT_PROLOGUE                                                        \
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");               \
+    HIPCHECK(hipSetDevice(t->device));                                      \
+    HIPCHECK(hipStreamSynchronize(t->stream));
+
+int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out10) {
+    KAT_PROLOGUE
+    if (geom < 0 || geom >= t->ngeoms) return set_error(PTX_ERR_INVALID, "geom index out of range");
+    if (n <= 0) return PTX_OK;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHECK(hipMalloc(&d_in, sizeof(float) * 6 * (size_t)n));
+    HIPCHECK(hipMalloc(&d_out, sizeof(float) * 10 * (size_t)n));
+    HIPCHECK(hipMemcpy(d_in, rays6, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_geom, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), geom, n, d_in, d_out);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(out10, d_out, sizeof(float) * 10 * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out);
+    return PTX_OK;
+}
+
+int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32) {
+    KAT_PROLOGUE
+    if (n <= 0) return PTX_OK;
+    HostPath *d_p = nullptr; HostIsect *d_i = nullptr;
+    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
+    HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_intersect, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), n, d_p, d_i);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(d_p); hipFree(d_i);
+    return PTX_OK;
+}
+
+int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void *isects32, void *paths44) {
+    KAT_PROLOGUE
+    if (n <= 0) return PTX_OK;
+    HostPath *d_p = nullptr; HostIsect *d_i = nullptr; int32_t *d_x = nullptr;
+    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_x, sizeof(int32_t) * (size_t)n));
+    HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_i, isects32, sizeof(HostIsect) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_x, idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_shade, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), iter, n, d_x, d_i, d_p);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(d_p); hipFree(d_i); hipFree(d_x);
+    return PTX_OK;
+}
+
+int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44) {
+    KAT_PROLOGUE
+    int n = t->cam.resx * t->cam.resy;
+    HostPath *d_p = nullptr;
+    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
+    hipLaunchKernelGGL(k_kat_generate, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->cam, iter, t->traceDepth,
+                       t->opt.antialiasing, t->opt.depth_of_field, d_p);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(d_p);
+    return PTX_OK;
+}
+
+int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *cos_out, const double *pw_in,
+                 double *pow5_out, const float *powf_xy, float *powf_out) {
+    KAT_PROLOGUE
+    if (n <= 0) return PTX_OK;
+    float *dx, *ds, *dc, *dxy, *dpo; double *dpw, *dp5;
+    HIPCHECK(hipMalloc(&dx, 4 * (size_t)n)); HIPCHECK(hipMalloc(&ds, 4 * (size_t)n)); HIPCHECK(hipMalloc(&dc, 4 * (size_t)n));
+    HIPCHECK(hipMalloc(&dxy, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dpo, 4 * (size_t)n));
+    HIPCHECK(hipMalloc(&dpw, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dp5, 8 * (size_t)n));
+    HIPCHECK(hipMemcpy(dx, x, 4 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dpw, pw_in, 8 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dxy, powf_xy, 8 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kat_libm, dim3((n + 255) / 256), dim3(256), 0, t->stream, n, dx, ds, dc, dpw, dp5, dxy, dpo);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(sin_out, ds, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(cos_out, dc, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(pow5_out, dp5, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(powf_out, dpo, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(ds); hipFree(dc); hipFree(dxy); hipFree(dpo); hipFree(dpw); hipFree(dp5);
+    return PTX_OK;
+}
+
+int ptx_debug_set_capture(ptx_tracer *t, int bounce) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    HIPCHECK(hipSetDevice(t->device));
+    t->capture_bounce = bounce;
+    t->cap_filled = false;
+    if (bounce >= 0 && !t->d_cap) {
+        HIPCHECK(hipMalloc(&t->d_cap, sizeof(int32_t) * (3 * (size_t)t->cap + (size_t)t->nbins)));
+        HIPCHECK(hipMalloc(&t->d_cap_f, sizeof(float) * SOA_FLOATS * (size_t)t->cap));
+    }
+    return PTX_OK;
+}
+
+int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx, int32_t *material,
+                          float *fields15, int cap) {
+    if (!t || !n_out) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    *n_out = 0;
+    if (!t->cap_filled) return set_error(PTX_ERR_INVALID, "nothing captured");
+    std::vector<int32_t> tot((size_t)t->nbins);
+    HIPCHECK(hipMemcpy(tot.data(), t->d_cap + 3 * (size_t)t->cap, sizeof(int32_t) * tot.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int v : tot) n += v;
+    *n_out = n;
+    int m = n < cap ? n : cap;
+    if (m > 0) {
+        HIPCHECK(hipMemcpy(pixel_index, t->d_cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(stream_idx, t->d_cap + t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        std::vector<int32_t> mg((size_t)m);
+        HIPCHECK(hipMemcpy(mg.data(), t->d_cap + 2 * (size_t)t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        for (int k = 0; k < m; k++) material[k] = mg[k] & 0xffff;
+        if (fields15)       // 15 rows of m floats: ox oy oz dx dy dz cr cg cb t nx ny nz u v
+            for (int f = 0; f < SOA_FLOATS; f++)
+                HIPCHECK(hipMemcpy(fields15 + (size_t)f * m, t->d_cap_f + (size_t)f * t->cap, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+    }
+    return PTX_OK;
+}
+
+}  // extern "C"
