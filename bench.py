@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: Mrays/s and ms/iteration of the path-tracing bounce loop.
+
+Workload (BASELINE.json metric "Mrays/s ... at 1920x1080 depth-8", configs[3], SURVEY 8(d) "C4"): scenes/cornellObj.txt
+(6 boxes + a 12-triangle mesh) at 1920x1080, trace depth 8, antialiasing on, material sort on, 1 sample per pixel per
+step.  A step = one pathtrace(iter) over the whole frame.  Rays = paths entering the intersect stage, summed over
+bounces (the reference's own unit; about 5.37 M per step).  Inputs are resident in HBM before the timed region.
+
+    python bench.py                        # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W      # N ranks: interleaved row tiles + one RCCL reduce per run
+
+Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel, algorithmic bytes / measured launch time)
+and "cpu_baseline" (the oracle, single thread, on this host), see DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = "cornellObj.txt 1920x1080 depth 8, AA on, material sort on, 1 spp/step (BASELINE configs[3] / C4)"
+SCENE, RES, DEPTH = "cornellObj.txt", (1920, 1080), 8
+HBM_PEAK = 8.0e12                 # MI355X HBM3E spec peak, B/s (MI355X_MICROARCH.md)
+# algorithmic bytes per ray-bounce from the reference's record sizes: intersect 76 + shade 120 are what
+# k_bounce does, material sort 152 + compaction 88 what k_scan/k_move do; 436 in total for the loop
+BYTES_BOUNCE_KERNEL = 76 + 120
+BYTES_LOOP = 436
+
+
+def cpu_baseline(scene, iters):
+    """Single-thread CPU oracle on a bounded sample of the same workload (checker code, timed here as a baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpulibs import OracleLib
+    d = scene.dump()
+    O = OracleLib()
+    O.set_libm(0)
+    O.create(d, d["textures"])
+    O.pt_init()
+    t0 = time.time()
+    rays = 0
+    for it in range(1, iters + 1):
+        O.iterate(it)
+        rays += int(O.live_counts().sum())
+    dt = time.time() - t0
+    sec = O.stage_seconds()
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
+                sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
+                stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mygpuraytracer_amd as pt
+    from mygpuraytracer_amd import multigpu
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    scene = pt.Scene(os.path.join(ROOT, "scenes", SCENE), res=RES, depth=DEPTH)
+    scene.apply_runcuda_camera()
+    W, H = RES
+    image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
+    kw = dict(device=local_rank)
+    if world > 1:
+        kw.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
+    T = pt.Tracer(scene, external_image_ptr=image.data_ptr(), **kw)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    T.render(1, args.warmup)
+    T.synchronize()
+    if world > 1:                                   # warm the collective too
+        dist.reduce(image.clone(), dst=0, op=dist.ReduceOp.SUM)
+    rays0 = T.stats()["rays_total"]
+    barrier()
+    t0 = time.perf_counter()
+    T.render(args.warmup + 1, args.steps)           # EXACTLY K steps, enqueued back to back on the tracer's stream
+    T.synchronize()
+    if world > 1:                                   # one RCCL reduce of the accumulation buffer per run
+        dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = T.stats()
+    rays = st["rays_total"] - rays0
+    loop_ms = T.last_loop_ms()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        rr = torch.tensor([rays], dtype=torch.int64, device=device)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays = int(rr.item())
+
+    # roofline leg: the same K steps again with hipEvents around every launch (on the tracer's stream)
+    T.set_kernel_timing(True)
+    T.render(args.warmup + args.steps + 1, args.steps)
+    kt = T.kernel_times()
+    T.set_kernel_timing(False)
+    st2 = T.stats()
+    rays_leg = st2["rays_total"] - st["rays_total"]
+    rpb = st2["rays_per_bounce"]
+    names = {k: v for k, v in kt.items() if v[1] > 0}
+    dominant = max(names, key=lambda k: names[k][0]) if names else "k_bounce"
+    dom_ms, dom_n = kt[dominant]
+    if dominant == "k_bounce":
+        units = rays_leg * (sum(rpb[1:]) / max(sum(rpb), 1)) / max(dom_n, 1)       # rays per launch, bounces >= 1
+    else:
+        units = rays_leg * (rpb[0] / max(sum(rpb), 1)) / max(dom_n, 1)
+    avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    achieved = BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic_round1.json")
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get(dominant)
+        except Exception:
+            traffic = None
+    loop_achieved = BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel=dominant, achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=achieved / HBM_PEAK, traffic=traffic,
+                    avg_launch_us=avg_s * 1e6, launches=dom_n, units_per_launch=units,
+                    algorithmic_bytes_per_unit=BYTES_BOUNCE_KERNEL,
+                    loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / HBM_PEAK, bytes_per_ray=BYTES_LOOP,
+                              loop_ms_per_step=loop_ms / args.steps),
+                    kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()})
+
+    out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
+               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
+               data="synthetic",
+               config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb,
+                           parallelism=("1 GPU" if world == 1 else "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL reduce/run" % (world, multigpu.TILE_ROWS))),
+               roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)
+    T.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

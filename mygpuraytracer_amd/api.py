@@ -123,6 +123,8 @@ def load_library():
     L.ptx_get_stats.restype, L.ptx_get_stats.argtypes = i, [vp, C.POINTER(Stats)]
     L.ptx_owned_pixels.restype, L.ptx_owned_pixels.argtypes = i, [vp]
     L.ptx_stream.restype, L.ptx_stream.argtypes = vp, [vp]
+    L.ptx_set_kernel_timing.restype, L.ptx_set_kernel_timing.argtypes = i, [vp, i]
+    L.ptx_get_kernel_times.restype, L.ptx_get_kernel_times.argtypes = i, [vp, vp, vp]
     L.ptx_kat_geom_test.restype, L.ptx_kat_geom_test.argtypes = i, [vp, i, i, vp, vp]
     L.ptx_kat_compute_intersections.restype, L.ptx_kat_compute_intersections.argtypes = i, [vp, i, vp, vp]
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
@@ -330,6 +332,17 @@ class Tracer:
 
     def last_loop_ms(self):
         return float(self.lib.ptx_last_loop_ms(self.h))
+
+    def set_kernel_timing(self, on):
+        _check(self.lib.ptx_set_kernel_timing(self.h, int(bool(on))), "ptx_set_kernel_timing")
+
+    def kernel_times(self):
+        """{kernel: (total ms, launches)} since the last call (needs set_kernel_timing(True))."""
+        ms = np.zeros(4, np.float64)
+        n = np.zeros(4, np.int64)
+        _check(self.lib.ptx_get_kernel_times(self.h, _ptr(ms), _ptr(n)), "ptx_get_kernel_times")
+        names = ("k_bounce<first>", "k_bounce", "k_scan", "k_move")
+        return {nm: (float(ms[k]), int(n[k])) for k, nm in enumerate(names)}
 
     def owned_pixels(self):
         return self.lib.ptx_owned_pixels(self.h)

@@ -450,6 +450,11 @@ struct ptx_tracer {
     bool cache_valid = false;
     int64_t iterations = 0;
     double loop_ms_total = 0.0;
+    // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
+    bool ktiming = false;
+    std::vector<hipEvent_t> kev;                         // pairs (start, stop)
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_scan, 3 k_move
+    size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;
     int32_t *d_cap = nullptr;                            // pix, idx, mg [cap each] + totals
@@ -485,6 +490,7 @@ int free_tracer(ptx_tracer *t) {
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_totals); hipFree(t->d_cache_totals);
     hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f);
+    for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -502,6 +508,26 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
     int32_t *counts_all = t->d_counts, *counts_scat = t->d_counts + (size_t)nb * t->maxTiles;
     auto totals = [&](int bounce, int which) { return t->d_totals + ((size_t)bounce * 2 + which) * nb; };
 
+    // per-kernel timing brackets (only when switched on; costs two event records per launch)
+    auto kt_begin = [&](int kind) -> int {
+        if (!t->ktiming) return PTX_OK;
+        if (t->kev_used + 2 > t->kev.size()) {
+            hipEvent_t a, b2;
+            HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b2));
+            t->kev.push_back(a); t->kev.push_back(b2);
+        }
+        if (t->kev_kind.size() < t->kev.size() / 2) t->kev_kind.resize(t->kev.size() / 2);
+        t->kev_kind[t->kev_used / 2] = kind;
+        HIPCHECK(hipEventRecord(t->kev[t->kev_used], t->stream));
+        return PTX_OK;
+    };
+    auto kt_end = [&]() -> int {
+        if (!t->ktiming) return PTX_OK;
+        HIPCHECK(hipEventRecord(t->kev[t->kev_used + 1], t->stream));
+        t->kev_used += 2;
+        return PTX_OK;
+    };
+#define KT(kind, launch) do { int rc_ = kt_begin(kind); if (rc_ != PTX_OK) return rc_; launch; rc_ = kt_end(); if (rc_ != PTX_OK) return rc_; } while (0)
     if (fill_cache) HIPCHECK(hipMemsetAsync(t->d_emit_count, 0, sizeof(int32_t), t->stream));
     for (int b = 0; b < t->traceDepth; b++) {
         const bool first = b == 0;
@@ -525,15 +551,15 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
-        if (first) hipLaunchKernelGGL(k_bounce<true>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp);
-        else hipLaunchKernelGGL(k_bounce<false>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp);
+        if (first) KT(0, hipLaunchKernelGGL(k_bounce<true>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
+        else KT(1, hipLaunchKernelGGL(k_bounce<false>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
 
         ScanParams sp;
         sp.nbins = nb; sp.maxTiles = t->maxTiles; sp.first = first; sp.owned = t->tm.owned;
         sp.totals_prev = bp.totals_prev;
         sp.counts_all = counts_all; sp.counts_scat = counts_scat;
         sp.totals_all = totals(b, 0); sp.totals_scat = totals(b, 1);
-        hipLaunchKernelGGL(k_scan, dim3(nb, 2), dim3(1024), 0, t->stream, sp);
+        KT(2, hipLaunchKernelGGL(k_scan, dim3(nb, 2), dim3(1024), 0, t->stream, sp));
 
         if (b + 1 < t->traceDepth) {
             MoveParams mp;
@@ -543,7 +569,7 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
             mp.totals_prev = bp.totals_prev;
             mp.counts_all = counts_all; mp.counts_scat = counts_scat;
             mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
-            hipLaunchKernelGGL(k_move, dim3(t->grid), dim3(TILE), lds_move, t->stream, mp);
+            KT(3, hipLaunchKernelGGL(k_move, dim3(t->grid), dim3(TILE), lds_move, t->stream, mp));
         }
         if (first && fill_cache) {
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, t->stream));
@@ -910,6 +936,30 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
     HIPCHECK(hipMemcpy(pow5_out, dp5, 8 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(powf_out, dpo, 4 * (size_t)n, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(ds); hipFree(dc); hipFree(dxy); hipFree(dpo); hipFree(dpw); hipFree(dp5);
+    return PTX_OK;
+}
+
+int ptx_set_kernel_timing(ptx_tracer *t, int on) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    t->ktiming = on != 0;
+    t->kev_used = 0;
+    return PTX_OK;
+}
+
+int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_by_kind[4]) {
+    if (!t || !ms_by_kind || !launches_by_kind) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    for (int k = 0; k < 4; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    for (size_t i = 0; i + 1 < t->kev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, t->kev[i], t->kev[i + 1]));
+        int kind = t->kev_kind[i / 2];
+        ms_by_kind[kind] += ms; launches_by_kind[kind]++;
+    }
+    t->kev_used = 0;
     return PTX_OK;
 }
 

@@ -1,0 +1,64 @@
+"""Row-tile sharding of one frame over the ranks of a torch.distributed job (one process per GPU, RCCL over xGMI).
+
+The reference has no multi-GPU code; this is the path north_star prescribes: every rank traces the
+row blocks it owns (interleaved blocks of TILE_ROWS rows, round-robin: the Cornell frame's cost per row is uneven,
+interleaving balances it), accumulating into a full-frame fp32 buffer in which rows it does not own stay zero; one
+``reduce(SUM)`` of that buffer to rank 0 per batch of iterations assembles the frame.  There is no collective on the
+data path itself -- tiles are independent streams.
+
+The renderer is injected so that the same driver runs on GPUs (``hip_tile_renderer``: the HIP tracer writing straight
+into the torch tensor that RCCL reduces) and, in the CPU tests, over gloo with a stand-in renderer.
+"""
+import torch
+import torch.distributed as dist
+
+TILE_ROWS = 16
+
+
+def owned_rows(height, tile_rows, rank, world):
+    """Rows y with (y // tile_rows) % world == rank -- the same rule the kernels apply (pt_engine.hip owned_pixel)."""
+    return [y for y in range(height) if (y // tile_rows) % world == rank]
+
+
+def render_distributed(renderer, width, height, iter_first, count, device, reduce_to=0):
+    """Runs `count` iterations of this rank's tile and reduces the accumulation buffers.
+
+    renderer(image_tensor, iter_first, count) must add this rank's radiance into image_tensor (flat W*H*3 fp32 on
+    `device`) and return the number of ray-bounces it traced.  Returns (image on reduce_to or None, total rays).
+    """
+    image = torch.zeros(width * height * 3, dtype=torch.float32, device=device)
+    rays = renderer(image, iter_first, count)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(image, dst=reduce_to, op=dist.ReduceOp.SUM)
+        total = torch.tensor([rays], dtype=torch.int64, device=device)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        rays = int(total.item())
+        if dist.get_rank() != reduce_to:
+            image = None
+    return image, rays
+
+
+def hip_tile_renderer(scene, rank, world, tile_rows=TILE_ROWS, **opt_kw):
+    """Builds the HIP tracer for this rank's tile; returns (renderer, make_tracer_for(image_tensor))."""
+    from . import api
+
+    state = {}
+
+    def renderer(image, iter_first, count):
+        if "tracer" not in state or state["ptr"] != image.data_ptr():
+            if "tracer" in state:
+                state["tracer"].close()
+            kw = dict(opt_kw)
+            if world > 1:
+                kw.update(tile_rows=tile_rows, tile_rank=rank, tile_world=world)
+            kw.setdefault("device", image.device.index if image.device.index is not None else 0)
+            state["tracer"] = api.Tracer(scene, external_image_ptr=image.data_ptr(), **kw)
+            state["ptr"] = image.data_ptr()
+        t = state["tracer"]
+        before = t.stats()["rays_total"]
+        t.render(iter_first, count)
+        t.synchronize()
+        return t.stats()["rays_total"] - before
+
+    renderer.state = state
+    return renderer

@@ -247,6 +247,7 @@ typedef struct {
     o_camera cam;
     int traceDepth;
     int opt_aa, opt_dof, opt_sort, opt_cache;
+    int tile_rows, tile_rank, tile_world;   /* multi-GPU row-tile split (not in the reference): 0,0,1 = whole frame */
     /* iteration state (pathtrace.cu:91-98) */
     int pixelcount, num_paths, depth;
     float *image;
@@ -272,6 +273,7 @@ void *o_scene_create(int ngeoms, const int *gints3, const float *gmats48, int nm
     }
     memcpy(s->mats, mats11, sizeof(o_material) * (size_t)nmat);
     s->opt_aa = 1; s->opt_dof = 0; s->opt_sort = 1; s->opt_cache = 1;   /* pathtrace.cu:36-40 */
+    s->tile_rows = 0; s->tile_rank = 0; s->tile_world = 1;
     return s;
 }
 static void free_iter_state(o_scene *s) {
@@ -311,6 +313,17 @@ void o_scene_set_camera(void *h, const int res2[2], const float f19[19], int tra
     memcpy(s->cam.position, f19, sizeof(float) * 19);
     s->traceDepth = traceDepth;
 }
+/* Row-tile split used by the multi-GPU driver: this instance traces only the rows y with
+ * (y / rows) % world == rank, as its own stream (local stream indices); pixelIndex stays global. */
+void o_scene_set_tile(void *h, int rows, int rank, int world) {
+    o_scene *s = (o_scene *)h;
+    s->tile_rows = rows; s->tile_rank = rank; s->tile_world = world < 1 ? 1 : world;
+}
+static int row_owned(const o_scene *s, int y) {
+    if (s->tile_world <= 1) return 1;
+    return (y / s->tile_rows) % s->tile_world == s->tile_rank;
+}
+
 void o_scene_set_options(void *h, int aa, int dof, int sort, int cache) {
     o_scene *s = (o_scene *)h;
     s->opt_aa = aa; s->opt_dof = dof; s->opt_sort = sort; s->opt_cache = cache;
@@ -802,9 +815,11 @@ static double now_s(void) {
 void o_pt_init(void *h) {
     o_scene *s = (o_scene *)h;
     free_iter_state(s);
-    s->pixelcount = s->cam.resx * s->cam.resy;
+    s->pixelcount = 0;
+    for (int y = 0; y < s->cam.resy; y++) if (row_owned(s, y)) s->pixelcount += s->cam.resx;
     size_t n = (size_t)(s->pixelcount > 0 ? s->pixelcount : 1);
-    s->image = (float *)calloc(n * 3, sizeof(float));
+    size_t nfull = (size_t)s->cam.resx * (size_t)s->cam.resy;
+    s->image = (float *)calloc((nfull > 0 ? nfull : 1) * 3, sizeof(float));
     s->paths = (o_path *)calloc(n, sizeof(o_path));
     s->paths_tmp = (o_path *)calloc(n, sizeof(o_path));
     s->isects = (o_isect *)calloc(n, sizeof(o_isect));
@@ -820,9 +835,11 @@ void o_pt_init(void *h) {
 void o_pt_generate(void *h, int iter) {
     o_scene *s = (o_scene *)h;
     double t0 = now_s();
-    for (int y = 0; y < s->cam.resy; y++)
-        for (int x = 0; x < s->cam.resx; x++)
-            generate_one(s, iter, s->traceDepth, x, y, &s->paths[x + y * s->cam.resx]);
+    int k = 0;
+    for (int y = 0; y < s->cam.resy; y++) {
+        if (!row_owned(s, y)) continue;
+        for (int x = 0; x < s->cam.resx; x++) generate_one(s, iter, s->traceDepth, x, y, &s->paths[k++]);
+    }
     s->num_paths = s->pixelcount;
     s->depth = 0;
     s->nlive = 0;
@@ -939,12 +956,14 @@ o_isect *o_pt_isects(void *h) { return ((o_scene *)h)->isects; }
 float *o_pt_image(void *h) { return ((o_scene *)h)->image; }
 int o_pt_num_paths(void *h) { return ((o_scene *)h)->num_paths; }
 int o_pt_pixelcount(void *h) { return ((o_scene *)h)->pixelcount; }
+int o_pt_framepixels(void *h) { return ((o_scene *)h)->cam.resx * ((o_scene *)h)->cam.resy; }
 void o_pt_stage_seconds(void *h, double out6[6]) { memcpy(out6, ((o_scene *)h)->secs, sizeof(double) * 6); }
 
 /* pathtrace.cu:69-89 */
 void o_pt_pbo(void *h, int iter, unsigned char *pbo) {
     o_scene *s = (o_scene *)h;
-    for (int index = 0; index < s->pixelcount; index++) {
+    const int npix = s->cam.resx * s->cam.resy;
+    for (int index = 0; index < npix; index++) {
         const float *pix = s->image + (size_t)index * 3;
         int c[3];
         for (int k = 0; k < 3; k++) {

@@ -9,7 +9,9 @@
  * calls) this restatement is bit-identical to it on every fixture in tests/golden and on full frames
  * (tests/test_oracle_pin.py).  With o_set_libm(1) the four libm calls are replaced by the portable
  * IEEE-only routines the HIP kernels use (own_sincos / own_pow5 / own_powf below), so that GPU == oracle
- * bit for bit; the two modes differ by at most 1 ulp in those calls (tests/test_own_libm.py).
+ * bit for bit; the two modes differ by at most 1 ulp in those calls (the portable ones are correctly rounded,
+ * glibc's sinf/cosf are off by one ulp on ~1.3 % of arguments: tests/test_own_libm.py) and make the same
+ * hit/miss/material decisions on whole frames (tests/test_oracle_pin.py).
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
@@ -65,6 +67,7 @@ void o_scene_set_faces(void *s, int gi, int nfaces, const float *faces15);
 void o_scene_set_texture(void *s, int gi, int which, int w, int h, int ch, const unsigned char *data);
 void o_scene_set_camera(void *s, const int res2[2], const float f19[19], int traceDepth);
 void o_scene_set_options(void *s, int aa, int dof, int sort, int cache);
+void o_scene_set_tile(void *s, int rows, int rank, int world);   /* multi-GPU row tiles; 0,0,1 = whole frame */
 
 /* per-function entry points; same record layouts as oracle/ref_driver.cpp */
 void o_geom_test(void *s, int gi, int n, const float *rays6, float *out10);
@@ -82,7 +85,8 @@ o_path *o_pt_paths(void *s);
 o_isect *o_pt_isects(void *s);
 float *o_pt_image(void *s);
 int o_pt_num_paths(void *s);
-int o_pt_pixelcount(void *s);
+int o_pt_pixelcount(void *s);      /* pixels this instance traces (its tile) */
+int o_pt_framepixels(void *s);     /* W*H: size of the image buffer */
 void o_pt_pbo(void *s, int iter, unsigned char *pbo);
 /* seconds spent per stage since o_pt_init: intersect, sort, shade, compact, generate, gather */
 void o_pt_stage_seconds(void *s, double out6[6]);

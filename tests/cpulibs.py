@@ -140,6 +140,9 @@ class _Tracer:
     def num_paths(self):
         return self._f("pt_num_paths")(self.h)
 
+    def framepixels(self):
+        return self.pixelcount()
+
     def paths(self):
         n = self.pixelcount()
         addr = self._f("pt_paths")(self.h)
@@ -151,12 +154,12 @@ class _Tracer:
         return np.ctypeslib.as_array((C.c_char * (32 * n)).from_address(addr)).view(ISECT_DTYPE).copy()
 
     def image(self):
-        n = self.pixelcount()
+        n = self.framepixels()
         addr = self._f("pt_image")(self.h)
         return np.ctypeslib.as_array((C.c_float * (3 * n)).from_address(addr)).reshape(n, 3).copy()
 
     def pbo(self, it):
-        out = np.zeros((self.pixelcount(), 4), np.uint8)
+        out = np.zeros((self.framepixels(), 4), np.uint8)
         self._f("pt_pbo")(self.h, it, _ptr(out))
         return out
 
@@ -262,6 +265,8 @@ class OracleLib(_Tracer):
         L.o_scene_set_texture.argtypes = [vp, i, i, i, i, i, vp]
         L.o_scene_set_camera.argtypes = [vp, vp, vp, i]
         L.o_scene_set_options.argtypes = [vp, i, i, i, i]
+        L.o_scene_set_tile.argtypes = [vp, i, i, i]
+        L.o_pt_framepixels.restype, L.o_pt_framepixels.argtypes = i, [vp]
         L.o_pt_stage_seconds.argtypes = [vp, vp]
         for n in ("o_sc_scan",):
             getattr(L, n).argtypes = [i, vp, vp]
@@ -309,6 +314,12 @@ class OracleLib(_Tracer):
 
     def set_options(self, aa=1, dof=0, sort=1, cache=1):
         self.lib.o_scene_set_options(self.h, aa, dof, sort, cache)
+
+    def set_tile(self, rows, rank, world):
+        self.lib.o_scene_set_tile(self.h, rows, rank, world)
+
+    def framepixels(self):
+        return self.lib.o_pt_framepixels(self.h)
 
     def stage_seconds(self):
         out = np.zeros(6, np.float64)

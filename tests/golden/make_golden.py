@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE itself (oracle/_ref/libptref.so = the reference's own headers and
+loader compiled from /root/reference; see oracle/Makefile).  Run in the dev container only:
+
+    python tests/golden/make_golden.py
+
+The fixtures are data (inputs + expected outputs); no reference source text is stored.  Everything is seeded, so a
+re-run reproduces the files bit for bit.  Consumers: tests/test_oracle_golden.py (CPU, pins the plain-C oracle),
+tests/test_loader.py (CPU, pins the product's scene loader), tests/test_gpu_parity.py (GPU).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from cpulibs import RefLib, build_ref, scene_text_with, REFERENCE_ROOT, PATH_DTYPE, ISECT_DTYPE  # noqa: E402
+
+SCENES = ["sphere.txt", "cornell.txt", "cornellGlass.txt", "cornellObj.txt"]
+
+MIRROR_SCENE = """MATERIAL 0
+RGB         1 1 1
+SPECEX      0
+SPECRGB     0 0 0
+REFL        0
+REFR        0
+REFRIOR     0
+EMITTANCE   5
+
+MATERIAL 1
+RGB         .98 .98 .98
+SPECEX      0
+SPECRGB     0 0 0
+REFL        0
+REFR        0
+REFRIOR     0
+EMITTANCE   0
+
+MATERIAL 2
+RGB         .9 .9 .9
+SPECEX      %s
+SPECRGB     .95 .9 .85
+REFL        1
+REFR        0
+REFRIOR     0
+EMITTANCE   0
+
+CAMERA
+RES         64 64
+FOVY        45
+ITERATIONS  10
+DEPTH       8
+FILE        mirror
+EYE         0.0 5 10.5
+LOOKAT      0 5 0
+UP          0 1 0
+
+OBJECT 0
+cube
+material 0
+TRANS       0 10 0
+ROTAT       0 0 0
+SCALE       6 .3 6
+
+OBJECT 1
+cube
+material 1
+TRANS       0 0 0
+ROTAT       0 0 0
+SCALE       10 .01 10
+
+OBJECT 2
+sphere
+material 2
+TRANS       -1 4 -1
+ROTAT       0 0 0
+SCALE       5 5 5
+
+OBJECT 3
+cube
+material 2
+TRANS       3 2 1
+ROTAT       10 30 0
+SCALE       2 4 2
+"""
+
+
+def ref_text(name, res=None, depth=None):
+    return scene_text_with(open(os.path.join(REFERENCE_ROOT, "scenes", name)).read(), res, depth)
+
+
+def random_rays(rng, n, centre, radius):
+    """Rays aimed around a geom: random origins outside/inside, random + axis-parallel + degenerate directions."""
+    o = centre + rng.normal(size=(n, 3)) * radius * 2.0
+    o[: n // 8] = centre + rng.normal(size=(n // 8, 3)) * radius * 0.2          # origins inside
+    target = centre + rng.normal(size=(n, 3)) * radius * 0.6
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n // 16
+    axes = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1))
+    d[n // 8: n // 8 + k] = axes                                                 # axis-parallel (zero components)
+    d[-8:] *= rng.uniform(0.1, 10.0, (8, 1))                                     # unnormalised directions
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def main():
+    so = build_ref()
+    if not so:
+        sys.exit("oracle/_ref/libptref.so cannot be built here (no /root/reference)")
+    R = RefLib(so)
+    rng = np.random.default_rng(20261004)
+
+    # ---- hash + RNG -------------------------------------------------------------------------------------------
+    hin = np.concatenate([np.arange(64), rng.integers(0, 2**32, 192, dtype=np.uint64)]).astype(np.uint32)
+    hout = np.array([R.utilhash(int(v)) for v in hin], np.uint32)
+    triples = np.stack([rng.integers(1, 5001, 256), rng.integers(0, 3840 * 2160, 256), rng.integers(0, 13, 256)], 1).astype(np.int32)
+    triples[:4] = [[1, 0, 0], [1, 12345, 0], [5000, 2073599, 8], [2, 1, 12]]
+    raw = np.stack([R.rng_raw(*map(int, t), 4) for t in triples])
+    u01 = np.stack([R.rng_uniform(*map(int, t), 0.0, 1.0, 4) for t in triples])
+    uaa = np.stack([R.rng_uniform(*map(int, t), -0.5, 0.5, 4) for t in triples])
+    np.savez_compressed(os.path.join(HERE, "rng_kat.npz"), hash_in=hin, hash_out=hout, triples=triples, raw=raw, u01=u01, uaa=uaa)
+
+    # ---- loader dumps -----------------------------------------------------------------------------------------
+    for name in SCENES:
+        R.load(os.path.join(REFERENCE_ROOT, "scenes", name))
+        d = R.dump()
+        R.apply_runcuda_camera()
+        d2 = R.dump()
+        R.load_text(ref_text(name, (1920, 1080)))
+        d3 = R.dump()
+        out = dict(geom_ints=d["geom_ints"], geom_trs=d["geom_trs"], geom_mats=d["geom_mats"], materials=d["materials"],
+                   cam_ints=d["cam_ints"], cam_floats=d["cam_floats"], cam_floats_runcuda=d2["cam_floats"],
+                   cam_floats_1080p=d3["cam_floats"], texture_vector_sizes=d["texture_vector_sizes"])
+        for gi, f in enumerate(d["faces"]):
+            out["faces_%d" % gi] = f
+        np.savez_compressed(os.path.join(HERE, "loader_%s.npz" % name[:-4]), **out)
+
+    # ---- per-geom intersection KATs -----------------------------------------------------------------------------
+    for name in ("cornellGlass.txt", "cornellObj.txt"):
+        R.load(os.path.join(REFERENCE_ROOT, "scenes", name))
+        d = R.dump()
+        out = {}
+        for gi in range(len(d["geom_ints"])):
+            centre = d["geom_trs"][gi][:3].astype(np.float64)
+            radius = float(np.max(np.abs(d["geom_trs"][gi][6:9]))) * 0.6 + 0.2
+            rays = random_rays(rng, 1024, centre, radius)
+            out["rays_%d" % gi] = rays
+            out["out_%d" % gi] = R.geom_test(gi, rays)
+        np.savez_compressed(os.path.join(HERE, "isect_kat_%s.npz" % name[:-4]), **out)
+
+    # ---- shade / scatterRay KATs: real (path, intersection) pairs captured mid-render -----------------------------
+    cases = [("glass", ref_text("cornellGlass.txt", (48, 48), 8)), ("obj", ref_text("cornellObj.txt", (48, 48), 8)),
+             ("mirror0", MIRROR_SCENE % "0"), ("mirror20", MIRROR_SCENE % "20.5")]
+    for tag, text in cases:
+        R.load_text(text)
+        R.apply_runcuda_camera()
+        R.pt_init()
+        out = {}
+        for it in (1, 3):
+            R.pt_generate(it)
+            for b in range(3):
+                n = R.num_paths()
+                R.pt_bounce(it, 3)                                     # intersect + sort
+                paths, isects = R.paths()[:n], R.isects()[:n]
+                R.pt_bounce(it, 12)                                    # shade + partition
+                idx = rng.integers(0, 2_000_000, n).astype(np.int32)   # arbitrary stream indices for the KAT itself
+                shaded = R.shade(it, b + 1, idx, isects, paths)
+                key = "it%d_b%d" % (it, b)
+                out[key + "_paths"], out[key + "_isects"], out[key + "_idx"], out[key + "_shaded"] = paths, isects, idx, shaded
+                if R.num_paths() == 0:
+                    break
+        out["scene_text"] = np.frombuffer(text.encode(), np.uint8) if tag.startswith("mirror") else np.zeros(0, np.uint8)
+        np.savez_compressed(os.path.join(HERE, "shade_kat_%s.npz" % tag), **out)
+
+    # ---- small full renders: images, per-bounce live counts, per-bounce sorted streams ----------------------------
+    configs = [
+        ("c1_sphere", ref_text("sphere.txt", (64, 64), 4), dict(aa=1, dof=0, sort=1, cache=1)),
+        ("c2_cornell_cache", ref_text("cornell.txt", (64, 64), 8), dict(aa=0, dof=0, sort=1, cache=1)),
+        ("c3_glass", ref_text("cornellGlass.txt", (96, 54), 12), dict(aa=1, dof=0, sort=1, cache=1)),
+        ("c4_obj", ref_text("cornellObj.txt", (96, 54), 8), dict(aa=1, dof=0, sort=1, cache=1)),
+        ("c5_dof", ref_text("cornellGlass.txt", (96, 54), 8), dict(aa=1, dof=1, sort=1, cache=1)),
+        ("nosort_obj", ref_text("cornellObj.txt", (96, 54), 8), dict(aa=1, dof=0, sort=0, cache=0)),
+        ("mirror20", MIRROR_SCENE % "20.5", dict(aa=1, dof=0, sort=1, cache=1)),
+    ]
+    for tag, text, opt in configs:
+        R.load_text(text)
+        R.apply_runcuda_camera()
+        R.set_options(**opt)
+        R.pt_init()
+        out = dict(options=np.array([opt["aa"], opt["dof"], opt["sort"], opt["cache"]], np.int32))
+        for it in range(1, 17):
+            if it == 1:
+                # stream after intersect+sort of every bounce: pixel order, material ids (the RNG-visible permutation)
+                R.pt_generate(1)
+                b = 0
+                while True:
+                    n = R.num_paths()
+                    R.pt_bounce(1, 3)
+                    out["stream_pix_b%d" % b] = R.paths()["pixelIndex"][:n].copy()
+                    out["stream_mat_b%d" % b] = R.isects()["materialId"][:n].copy()
+                    out["stream_t_b%d" % b] = R.isects()["t"][:n].copy()
+                    if R.pt_bounce(1, 12) == 0:
+                        break
+                    b += 1
+                R.pt_final_gather()
+            else:
+                R.iterate(it)
+            if it in (1, 2, 16):
+                out["image_spp%d" % it] = R.image()
+                out["counts_it%d" % it] = R.live_counts()
+        out["pbo_spp16"] = R.pbo(16)
+        np.savez_compressed(os.path.join(HERE, "render_%s.npz" % tag), **out)
+
+    # ---- full-resolution live counts of iteration 1 (SURVEY 8(c) anchors, regenerated) ---------------------------
+    full = {}
+    for tag, name, res, depth, opt in [("c2", "cornell.txt", (800, 800), 8, dict(aa=0, dof=0, sort=1, cache=1)),
+                                       ("c3", "cornellGlass.txt", (1920, 1080), 12, dict(aa=1, dof=0, sort=1, cache=1)),
+                                       ("c4", "cornellObj.txt", (1920, 1080), 8, dict(aa=1, dof=0, sort=1, cache=1)),
+                                       ("c1", "sphere.txt", (256, 256), 4, dict(aa=1, dof=0, sort=1, cache=1))]:
+        R.load_text(ref_text(name, res, depth))
+        R.apply_runcuda_camera()
+        R.set_options(**opt)
+        R.pt_init()
+        R.iterate(1)
+        img = R.image()
+        full[tag + "_counts"] = R.live_counts()
+        full[tag + "_image_sum"] = img.sum(axis=0, dtype=np.float64)
+        full[tag + "_image_rowsum"] = img.reshape(res[1], res[0], 3).sum(axis=(1, 2), dtype=np.float64).astype(np.float64)
+        print(tag, R.live_counts().tolist(), img.mean(dtype=np.float64))
+    np.savez_compressed(os.path.join(HERE, "fullres_counts.npz"), **full)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

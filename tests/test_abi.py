@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol the headers in include/ declare; the
+product refuses to compute without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ptx|sc)_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header", ["mi355x_pathtracer.h", "mi355x_stream_compaction.h"])
+def test_every_declared_symbol_is_exported(product, header):
+    lib = ctypes.CDLL(product.LIB_PATH)
+    names = declared_symbols(header)
+    assert len(names) > 10
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_the_reference_records(product):
+    from mygpuraytracer_amd import api
+    assert ctypes.sizeof(api.Material) == 44            # struct Material, sceneStructs.h:71-81
+    assert ctypes.sizeof(api.Camera) == 84              # struct Camera ([probe] SURVEY 8)
+    assert ctypes.sizeof(api.Options) == 64
+
+
+def test_no_cpu_fallback(product):
+    lib = product.load_library()
+    if lib.ptx_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    s = product.Scene(os.path.join(ROOT, "scenes", "sphere.txt"))
+    with pytest.raises(product.PathTracerError):
+        product.Tracer(s)
+    sc = product.StreamCompaction()
+    with pytest.raises(product.PathTracerError):
+        sc.efficient_scan(np.arange(10, dtype=np.int32))
+    with pytest.raises(product.PathTracerError):
+        sc.efficient_compact(np.arange(10, dtype=np.int32))
+
+
+def test_cpu_stream_compaction_entry_points(product, oracle_lib):
+    """StreamCompaction::CPU::{scan, compactWithoutScan, compactWithScan} of the library vs numpy and the oracle."""
+    sc = product.StreamCompaction()
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 255, 256, 257, (1 << 20) - 3):
+        a = (rng.integers(0, 7, n) * rng.integers(0, 2, n)).astype(np.int32)
+        want = np.concatenate([[0], np.cumsum(a, dtype=np.int64)[:-1]]).astype(np.int32)
+        assert np.array_equal(sc.cpu_scan(a), want)
+        assert np.array_equal(sc.cpu_scan(a), oracle_lib.sc_scan(a))
+        assert np.array_equal(sc.cpu_compact_without_scan(a), a[a != 0])
+        assert np.array_equal(sc.cpu_compact_with_scan(a), a[a != 0])
+        assert sc.last_cpu_ms() >= 0.0
+    lib = product.load_library()
+    assert [lib.sc_ilog2(v) for v in (1, 2, 3, 4, 1023, 1024)] == [0, 1, 1, 2, 9, 10]
+    assert [lib.sc_ilog2ceil(v) for v in (1, 2, 3, 4, 1023, 1025)] == [0, 1, 2, 2, 10, 11]

@@ -1,0 +1,289 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+The oracle runs in its portable-libm mode (the sin/cos/pow routines the kernels run; pinned to the reference in
+tests/test_own_libm.py / test_oracle_pin.py); everything else about it is pinned to the reference by
+tests/test_oracle_golden.py.  Tolerance: none -- integer work and fp32 alike must match exactly, because the
+shading RNG is seeded by stream position and any flipped decision decorrelates the frame (hard parts).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, beq, golden
+from cpulibs import PATH_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(pt, O, scene, res, depth, **opt):
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=depth)
+    s.apply_runcuda_camera()
+    d = s.dump()
+    O.set_libm(1)
+    O.create(d, d["textures"])
+    O.set_options(aa=opt.get("antialiasing", 1), dof=opt.get("depth_of_field", 0), sort=opt.get("sort_by_material", 1),
+                  cache=opt.get("cache_first_bounce", 1))
+    O.pt_init()
+    return s, pt.Tracer(s, **opt)
+
+
+@pytest.fixture()
+def O(oracle_lib):
+    oracle_lib.set_libm(1)
+    yield oracle_lib
+    oracle_lib.set_libm(0)
+
+
+def test_device_libm_bit_identical(gpu_product, O):
+    s, T = make_pair(gpu_product, O, "sphere.txt", (16, 16), 2)
+    rng = np.random.default_rng(1)
+    n = 200000
+    x = np.concatenate([(rng.random(n - 7) * np.float32(6.2831855)).astype(np.float32),
+                        np.float32([0, 6.2831855, 3.1415927, 1.5707964, -0.7853982, 2.3561945, 1e-30])])
+    pw = rng.uniform(-0.5, 2.0, n)
+    pxy = np.stack([rng.random(n).astype(np.float32), rng.uniform(0, 120, n).astype(np.float32)], 1)
+    pxy[:6] = [[0, 0], [0, 2], [1, 5], [.5, 2], [2, 10], [.3, 0]]
+    sn, cs, p5, po = T.libm(x, pw, pxy)
+    for k in range(0, n, 37):
+        a, b = O.own_sincosf(x[k])
+        assert a.tobytes() == sn[k].tobytes() and b.tobytes() == cs[k].tobytes()
+        assert O.lib.o_own_pow5(float(pw[k])) == p5[k]
+        assert np.float32(O.lib.o_own_powf(float(pxy[k, 0]), float(pxy[k, 1]))).tobytes() == po[k].tobytes()
+    T.close()
+
+
+@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj"])
+def test_intersection_kats_on_device(gpu_product, O, scene):
+    """The golden per-geom vectors (produced by the reference's own box/sphere/mesh tests) through the device functions."""
+    k = golden("isect_kat_%s.npz" % scene)
+    s, T = make_pair(gpu_product, O, scene + ".txt", (16, 16), 8)
+    for gi in range(s.num_geoms):
+        out = T.geom_test(gi, k["rays_%d" % gi])
+        ref = k["out_%d" % gi]
+        hit = ref[:, 0] > 0
+        assert beq(out[:, 0], ref[:, 0]) and beq(out[hit], ref[hit])
+    T.close()
+
+
+@pytest.mark.parametrize("scene,res,depth,opt", [
+    ("sphere.txt", (64, 64), 4, {}),
+    ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),
+    ("cornellGlass.txt", (96, 54), 12, dict(depth_of_field=1)),
+    ("cornellObj.txt", (96, 54), 8, {}),
+])
+def test_stage_parity(gpu_product, O, scene, res, depth, opt):
+    """generateRayFromCamera, computeIntersections and shadeFakeMaterial one at a time on identical inputs."""
+    s, T = make_pair(gpu_product, O, scene, res, depth, **opt)
+    O.pt_generate(3)
+    op = O.paths()
+    assert beq(T.generate(3), op)
+    oi, gi = O.compute_intersections(op), T.compute_intersections(op)
+    hit = oi["t"] > 0
+    assert beq(gi["t"], oi["t"]) and beq(gi["materialId"], oi["materialId"])
+    assert beq(gi["normal"][hit], oi["normal"][hit]) and beq(gi["geomId"][hit], oi["geomId"][hit])
+    obj = hit & (s.dump()["geom_ints"][oi["geomId"], 0] == 3)
+    assert beq(gi["texcoord"][obj], oi["texcoord"][obj])
+    idx = np.random.default_rng(9).integers(0, 4_000_000, len(op)).astype(np.int32)
+    assert beq(T.shade(3, idx, oi, op), O.shade(3, 1, idx, oi, op))
+    # last bounce (remainingBounces == 1) and second scatter
+    op2 = O.shade(3, 1, idx, oi, op)
+    live = op2["remainingBounces"] > 0
+    p2 = op2[live]
+    p2["remainingBounces"][::3] = 1
+    oi2 = O.compute_intersections(p2)
+    assert beq(T.compute_intersections(p2)["t"], oi2["t"])
+    assert beq(T.shade(4, idx[: len(p2)], oi2, p2), O.shade(4, 2, idx[: len(p2)], oi2, p2))
+    T.close()
+
+
+@pytest.mark.parametrize("tag", ["glass", "obj", "mirror0", "mirror20"])
+def test_shade_golden_on_device(gpu_product, O, tag):
+    """Golden (path, intersection) -> shaded path vectors captured from reference renders.  The expected values were
+    produced with glibc's libm, the device runs the portable one: identical wherever no sin/cos/pow is involved
+    (mirror with exponent 0, refraction, lights, misses), within 2e-6 otherwise."""
+    from test_oracle_golden import _scene_for_shade
+    from test_loader import product_dump_from_text
+    import tempfile
+    k = golden("shade_kat_%s.npz" % tag)
+    if tag.startswith("mirror"):
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write(bytes(k["scene_text"]).decode())
+        s = gpu_product.Scene(f.name, base_dir=os.path.join(ROOT, "scenes"))
+        os.unlink(f.name)
+    else:
+        s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt" if tag == "glass" else "cornellObj.txt"))
+    T = gpu_product.Tracer(s)
+    _scene_for_shade(O, tag)
+    O.set_libm(1)
+    for key in sorted(x[:-6] for x in k.files if x.endswith("_paths")):
+        got = T.shade(int(key[2]), k[key + "_idx"], k[key + "_isects"], k[key + "_paths"])
+        assert beq(got, O.shade(int(key[2]), 1, k[key + "_idx"], k[key + "_isects"], k[key + "_paths"]))
+        want = k[key + "_shaded"]
+        assert beq(got["remainingBounces"], want["remainingBounces"]) and beq(got["pixelIndex"], want["pixelIndex"])
+        for f in ("origin", "direction", "color"):
+            assert np.allclose(got[f], want[f], rtol=2e-6, atol=2e-6), (key, f)    # fp32 tolerance for the libm swap
+            assert (got[f] == want[f]).mean() > 0.95                               # identical in the vast majority
+    T.close()
+
+
+def oracle_pending_stream(O, it, bounce):
+    """What the HIP path stores after bounce `bounce`: the paths that will scatter at bounce+1, in the reference's
+    sorted order, with their stream index (= position after intersect + sort) and pending intersection."""
+    O.pt_generate(it)
+    for _ in range(bounce + 1):
+        n = O.num_paths()
+        O.pt_bounce(it, 3)
+        paths, isects = O.paths()[:n], O.isects()[:n]
+        O.pt_bounce(it, 12)
+    return n, paths, isects
+
+
+@pytest.mark.parametrize("scene,res,depth,opt", [
+    ("cornellGlass.txt", (96, 54), 12, {}),
+    ("cornellObj.txt", (96, 54), 8, {}),
+    ("cornellObj.txt", (96, 54), 8, dict(sort_by_material=0)),
+    ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),
+])
+def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
+    """The permutation is the observable: after each bounce the device stream holds exactly the reference's sorted
+    survivors -- same pixels in the same order, same RNG stream index, same ray / colour / hit bits."""
+    s, T = make_pair(gpu_product, O, scene, res, depth, **opt)
+    mats = s.dump()["materials"]
+    it = 1
+    for bounce in range(min(depth - 1, 5)):
+        T.reset_image()
+        T.debug_capture(bounce)
+        T.pathtrace(it)
+        g = T.debug_stream()
+        n, paths, isects = oracle_pending_stream(O, it, bounce)
+        # bounce b's sorted array is shaded at shade index b: remainingBounces there = depth - b
+        pend = (isects["t"] > 0) & (mats[isects["materialId"], 10] <= 0) & (depth - bounce != 1)
+        want_idx = np.nonzero(pend)[0].astype(np.int32)
+        assert len(g["pix"]) == len(want_idx), (bounce, len(g["pix"]), len(want_idx))
+        assert beq(g["idx"], want_idx)
+        assert beq(g["pix"], paths["pixelIndex"][pend])
+        assert beq(g["mat"], isects["materialId"][pend])
+        for k, nm in enumerate(("ox", "oy", "oz")):
+            assert beq(g[nm], paths["origin"][pend][:, k])
+        for k, nm in enumerate(("dx", "dy", "dz")):
+            assert beq(g[nm], paths["direction"][pend][:, k])
+        for k, nm in enumerate(("cr", "cg", "cb")):
+            assert beq(g[nm], paths["color"][pend][:, k])
+        assert beq(g["t"], isects["t"][pend])
+        for k, nm in enumerate(("nx", "ny", "nz")):
+            assert beq(g[nm], isects["normal"][pend][:, k])
+    T.close()
+
+
+RENDER_CASES = [
+    ("c1_sphere", "sphere.txt", (64, 64), 4), ("c2_cornell_cache", "cornell.txt", (64, 64), 8), ("c3_glass", "cornellGlass.txt", (96, 54), 12),
+    ("c4_obj", "cornellObj.txt", (96, 54), 8), ("c5_dof", "cornellGlass.txt", (96, 54), 8), ("nosort_obj", "cornellObj.txt", (96, 54), 8),
+]
+
+
+@pytest.mark.parametrize("tag,scene,res,depth", RENDER_CASES)
+def test_images_match_reference_golden(gpu_product, O, tag, scene, res, depth):
+    """Accumulated radiance after 1, 2 and 16 iterations equals the reference's (golden, glibc libm) and the
+    oracle's bit for bit; so do the per-bounce ray counts and the 8-bit preview."""
+    r = golden("render_%s.npz" % tag)
+    aa, dof, sort, cache = map(int, r["options"])
+    s, T = make_pair(gpu_product, O, scene, res, depth, antialiasing=aa, depth_of_field=dof, sort_by_material=sort, cache_first_bounce=cache)
+    for it in range(1, 17):
+        O.iterate(it)
+        T.pathtrace(it)
+        if it in (1, 2, 16):
+            img = T.read_image()
+            assert beq(img, O.image())
+            assert np.array_equal(img, r["image_spp%d" % it])
+            counts = r["counts_it%d" % it]
+            got = T.stats()["rays_per_bounce"][: len(counts)]
+            if not (cache and not aa and not dof and it > 1):       # cached iterations do not re-trace bounce 0
+                assert got == counts.tolist()
+            else:
+                assert got[1:] == counts.tolist()[1:] and got[0] == 0
+    assert np.array_equal(T.pbo(16), r["pbo_spp16"])
+    T.close()
+
+
+def test_full_size_c4_counts_and_properties(gpu_product, O):
+    """BASELINE config 4 at full size (cornellObj 1920x1080 depth 8).  Rays per bounce of iteration 1 equal the
+    reference's (SURVEY 8(c) anchor); beyond that, size-independent properties: reruns are bit-identical, every pixel
+    is written at most once per iteration (image sum = per-iteration sums), batched == one-at-a-time."""
+    f = golden("fullres_counts.npz")
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(1920, 1080), depth=8)
+    s.apply_runcuda_camera()
+    T = gpu_product.Tracer(s)
+    T.pathtrace(1)
+    img1 = T.read_image()
+    assert T.stats()["rays_per_bounce"] == f["c4_counts"].tolist() == [2073600, 952877, 636958, 492327, 394775, 323704, 268423, 224735]
+    assert np.array_equal(img1.sum(axis=0, dtype=np.float64), f["c4_image_sum"])
+    assert np.array_equal(img1.reshape(1080, 1920, 3).sum(axis=(1, 2), dtype=np.float64), f["c4_image_rowsum"])
+    T.pathtrace(2)
+    img12 = T.read_image()
+    T.reset_image(); T.pathtrace(2)
+    img2 = T.read_image()
+    assert np.array_equal(img12, img1 + img2)                       # one add per pixel per iteration, in order
+    T.reset_image(); T.render(1, 2)
+    assert np.array_equal(T.read_image(), img12)                    # batched enqueue == two calls
+    T2 = gpu_product.Tracer(s)
+    T2.render(1, 2)
+    assert np.array_equal(T2.read_image(), img12)                   # a fresh tracer reproduces it
+    assert (img12 >= 0).all() and np.isfinite(img12).all()
+    T.close(); T2.close()
+
+
+def test_full_size_c4_against_oracle(gpu_product, O):
+    """One whole 1920x1080 iteration against the CPU oracle (about 4 s of CPU): identical image."""
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", (1920, 1080), 8)
+    O.iterate(1); T.pathtrace(1)
+    assert beq(T.read_image(), O.image())
+    assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
+    T.close()
+
+
+def test_tile_split_matches_oracle_on_the_same_tile(gpu_product, O):
+    """Multi-GPU row tiles: each tile is its own stream (local stream indices), so a tile must equal the oracle run
+    on that tile; the tiles together cover every pixel exactly once."""
+    res, depth = (96, 64), 8
+    covered = np.zeros(res[0] * res[1], bool)
+    total = np.zeros((res[0] * res[1], 3), np.float32)
+    for rank in range(3):
+        s, T = make_pair(gpu_product, O, "cornellObj.txt", res, depth, tile_rows=8, tile_rank=rank, tile_world=3)
+        O.set_tile(8, rank, 3); O.pt_init()
+        assert T.owned_pixels() == O.pixelcount()
+        for it in (1, 2):
+            O.iterate(it); T.pathtrace(it)
+        img = T.read_image()
+        assert beq(img, O.image())
+        rows = (np.arange(res[1]) // 8) % 3 == rank
+        mask = np.repeat(rows, res[0])
+        assert not img[~mask].any()
+        assert not (covered & mask).any()
+        covered |= mask; total += img
+        T.close()
+    assert covered.all()
+    O.set_tile(0, 0, 1)
+    # the assembled frame is a different (equally valid) random sequence than the 1-GPU frame: compare statistically
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", res, depth)
+    T.render(1, 2)
+    one = T.read_image()
+    assert abs(float(total.mean()) - float(one.mean())) < 0.05 * float(one.mean()) + 0.02
+    T.close()
+
+
+def test_error_paths(gpu_product):
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(32, 32), depth=0)
+    with pytest.raises(pt.PathTracerError):
+        pt.Tracer(s)
+    s.set_trace_depth(4)
+    with pytest.raises(pt.PathTracerError):
+        pt.Tracer(s, bounding_box=1)
+    with pytest.raises(pt.PathTracerError):
+        pt.Tracer(s, tile_rows=0, tile_rank=0, tile_world=2)
+    T = pt.Tracer(s)
+    s2 = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(64, 32), depth=4)
+    with pytest.raises(pt.PathTracerError):
+        T.set_camera(s2)                       # resolution is fixed at init, as in the reference
+    T.close(); T.close()                       # pathtraceFree is idempotent

@@ -1,0 +1,105 @@
+"""CPU: the product's scene loader (C ABI ptx_scene_*, no GPU needed) against loader dumps produced by the
+reference's own Scene class (tests/golden/loader_*.npz)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, beq, golden
+
+SCENES = ["sphere", "cornell", "cornellGlass", "cornellObj"]
+
+
+def product_dump_from_text(text, runcuda=False, base_dir=None):
+    import mygpuraytracer_amd as pt
+    pt.build_library()
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write(text)
+    try:
+        s = pt.Scene(f.name, base_dir=base_dir or os.path.join(ROOT, "scenes"))
+    finally:
+        os.unlink(f.name)
+    if runcuda:
+        s.apply_runcuda_camera()
+    return s.dump()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_loader_matches_reference_dump(product, scene):
+    g = golden("loader_%s.npz" % scene)
+    s = product.Scene(os.path.join(ROOT, "scenes", scene + ".txt"))
+    d = s.dump()
+    for k in ("geom_ints", "geom_trs", "geom_mats", "materials", "cam_ints", "cam_floats"):
+        assert beq(d[k], g[k]), k
+    for gi, f in enumerate(d["faces"]):
+        assert beq(f, g["faces_%d" % gi])
+    assert s.image_name == ("sphere" if scene == "sphere" else "cornell")
+    s.apply_runcuda_camera()
+    assert beq(s.dump()["cam_floats"], g["cam_floats_runcuda"])
+    s2 = product.Scene(os.path.join(ROOT, "scenes", scene + ".txt"), res=(1920, 1080))
+    assert beq(s2.dump()["cam_floats"], g["cam_floats_1080p"])
+
+
+def test_obj_has_own_material_and_empty_textures(product):
+    """cornellObj: the OBJ geom gets a material appended from the first .mtl entry (scene.cpp:221-231) and four
+    empty texture slots (the reference's scene-wide texture vectors are one short here: fixture says 6 < 7)."""
+    g = golden("loader_cornellObj.npz")
+    assert list(g["texture_vector_sizes"]) == [6, 6, 6, 6] and len(g["geom_ints"]) == 7
+    d = product.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt")).dump()
+    assert d["geom_ints"][6].tolist() == [3, 6, 12] and len(d["materials"]) == 7 and not d["textures"]
+
+
+def test_line_endings_and_missing_final_newline(product):
+    text = open(os.path.join(ROOT, "scenes", "cornell.txt")).read().rstrip("\n")
+    base = product_dump_from_text(text)
+    for variant in (text.replace("\n", "\r\n"), text.replace("\n", "\r")):
+        d = product_dump_from_text(variant)
+        assert beq(d["geom_mats"], base["geom_mats"]) and beq(d["materials"], base["materials"]) and beq(d["cam_floats"], base["cam_floats"])
+
+
+@pytest.mark.parametrize("mutate, needle", [
+    (lambda t: t.replace("MATERIAL 1", "MATERIAL 7", 1), "MATERIAL id"),
+    (lambda t: t.replace("OBJECT 1", "OBJECT 9", 1), "OBJECT id"),
+    (lambda t: t.replace("cube\n", "torus\n", 1), "unknown object type"),
+    (lambda t: t.replace("SPECEX      0\n", "\n", 1), "MATERIAL block"),
+    (lambda t: t.replace("material 3", "material 42"), "material that does not exist"),
+    (lambda t: t[: t.index("// camera")], "no CAMERA"),
+])
+def test_malformed_scenes_are_rejected(product, mutate, needle):
+    text = mutate(open(os.path.join(ROOT, "scenes", "cornell.txt")).read())
+    with pytest.raises(product.PathTracerError) as e:
+        product_dump_from_text(text)
+    assert needle in str(e.value)
+
+
+def test_missing_files(product):
+    with pytest.raises(product.PathTracerError):
+        product.Scene("/nonexistent/scene.txt")
+    text = open(os.path.join(ROOT, "scenes", "cornellObj.txt")).read().replace("cube.obj", "nope.obj")
+    with pytest.raises(product.PathTracerError) as e:
+        product_dump_from_text(text)
+    assert "nope.obj" in str(e.value)
+
+
+def test_ppm_textures_and_quad_split(product, tmp_path):
+    """OBJ with uv + map_Kd/map_Ke PPM textures: texels arrive flipped vertically (stbi flip), quads split along the
+    shorter diagonal."""
+    (tmp_path / "scenes").mkdir(); (tmp_path / "models" / "materials").mkdir(parents=True); (tmp_path / "textures").mkdir()
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)           # h=2, w=3
+    with open(tmp_path / "textures" / "t.ppm", "wb") as f:
+        f.write(b"P6\n3 2\n255\n" + img.tobytes())
+    (tmp_path / "models" / "materials" / "q.mtl").write_text("newmtl a\nKd .1 .2 .3\nKs .4 .5 .6\nNi 1.5\nmap_Kd ..\\\\textures\\\\t.ppm\nmap_Ke ../textures/t.ppm\n")
+    (tmp_path / "models" / "q.obj").write_text("mtllib q.mtl\nv 0 0 0\nv 3 0 0\nv 3 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\nf 1/1 2/2 3/3\n")
+    text = open(os.path.join(ROOT, "scenes", "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/q.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n"
+    (tmp_path / "scenes" / "s.txt").write_text(text)
+    d = product.Scene(str(tmp_path / "scenes" / "s.txt")).dump()
+    assert d["geom_ints"][1].tolist() == [3, 1, 3]
+    f = d["faces"][1]
+    # |v2-v0|^2 = 10 == |v3-v1|^2 = 10 -> tie -> [0,1,3],[1,2,3]
+    assert f[0].reshape(3, 5)[:, :3].tolist() == [[0, 0, 0], [3, 0, 0], [0, 1, 0]]
+    assert f[1].reshape(3, 5)[:, :3].tolist() == [[3, 0, 0], [3, 1, 0], [0, 1, 0]]
+    assert f[0].reshape(3, 5)[:, 3:].tolist() == [[0, 0], [1, 0], [0, 1]]
+    assert np.allclose(d["materials"][1], [.1, .2, .3, 0, .4, .5, .6, 0, 0, 1.5, 0])
+    assert set(d["textures"]) == {(1, 0), (1, 2)}
+    assert np.array_equal(d["textures"][(1, 0)], img[::-1])
