@@ -1,0 +1,100 @@
+"""CPU: the N>1 host path (mygpuraytracer_amd/multigpu.py) with world_size 2 over gloo.  The HIP renderer is replaced
+by the CPU oracle restricted to the rank's row tiles, so what is tested is the driver: the ownership rule, the
+full-frame accumulation buffers with foreign rows left zero, the reduce to rank 0 and the ray total."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import HERE, ROOT, golden, dump_from_golden
+
+RES, DEPTH, ROWS, ITERS = (48, 40), 6, 4, 2
+
+
+def _scene_dump(O):
+    g = golden("loader_cornellObj.npz")
+    d = dump_from_golden(g, cam="cam_floats")
+    cf = d["cam_floats"]
+    d["cam_floats"] = O.camera_from_loader(RES[0], RES[1], float(cf[16]), cf[0:3], cf[3:6], cf[9:12])
+    ci = d["cam_ints"].copy(); ci[0], ci[1], ci[3] = RES[0], RES[1], DEPTH
+    d["cam_ints"] = ci
+    return d
+
+
+def _oracle_tile(rank, world):
+    sys.path.insert(0, HERE)
+    from cpulibs import OracleLib
+    O = OracleLib()
+    O.set_libm(1)
+    O.create(_scene_dump(O)); O.apply_runcuda_camera()
+    O.set_tile(ROWS, rank, world)
+    O.pt_init()
+    rays = 0
+    for it in range(1, ITERS + 1):
+        O.iterate(it)
+        rays += int(O.live_counts().sum())
+    return O.image().reshape(-1).copy(), rays, O.pixelcount()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mygpuraytracer_amd import multigpu
+
+    def renderer(image, iter_first, count):
+        assert (iter_first, count) == (1, ITERS)
+        img, rays, owned = _oracle_tile(rank, world)
+        assert owned == len(multigpu.owned_rows(RES[1], ROWS, rank, world)) * RES[0]
+        image += torch.from_numpy(img)
+        return rays
+
+    image, rays = multigpu.render_distributed(renderer, RES[0], RES[1], 1, ITERS, torch.device("cpu"))
+    q.put((rank, None if image is None else image.numpy().copy(), rays))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_render_and_reduce():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, img, rays = q.get(timeout=180)
+        got[rank] = (img, rays)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1][0] is None and got[0][0] is not None
+    tiles = [_oracle_tile(r, 2) for r in range(2)]
+    want = tiles[0][0] + tiles[1][0]
+    assert np.array_equal(got[0][0], want)
+    assert got[0][1] == got[1][1] == tiles[0][1] + tiles[1][1]
+    # the two tiles are disjoint and cover the frame
+    a, b = tiles[0][0].reshape(RES[1], RES[0] * 3), tiles[1][0].reshape(RES[1], RES[0] * 3)
+    from mygpuraytracer_amd import multigpu
+    r0, r1 = multigpu.owned_rows(RES[1], ROWS, 0, 2), multigpu.owned_rows(RES[1], ROWS, 1, 2)
+    assert sorted(r0 + r1) == list(range(RES[1])) and not set(r0) & set(r1)
+    assert not a[r1].any() and not b[r0].any()
+
+
+def test_owned_rows_rule():
+    from mygpuraytracer_amd import multigpu
+    for H, rows, world in ((1080, 16, 8), (1080, 16, 3), (7, 4, 2), (2160, 8, 8)):
+        seen = []
+        for r in range(world):
+            seen += multigpu.owned_rows(H, rows, r, world)
+        assert sorted(seen) == list(range(H))
+    # balance at the bench geometry: 1080 rows, 16-row blocks, 8 ranks -> 128..144 rows each
+    sizes = [len(multigpu.owned_rows(1080, 16, r, 8)) for r in range(8)]
+    assert max(sizes) - min(sizes) <= 16
