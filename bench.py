@@ -26,7 +26,7 @@ WORKLOAD = "cornellObj.txt 1920x1080 depth 8, AA on, material sort on, 1 spp/ste
 SCENE, RES, DEPTH = "cornellObj.txt", (1920, 1080), 8
 HBM_PEAK = 8.0e12                 # MI355X HBM3E spec peak, B/s (MI355X_MICROARCH.md)
 # algorithmic bytes per ray-bounce from the reference's record sizes: intersect 76 + shade 120 are what
-# k_bounce does, material sort 152 + compaction 88 what k_scan/k_move do; 436 in total for the loop
+# k_bounce does, material sort 152 + compaction 88 what k_move does; 436 in total for the loop
 BYTES_BOUNCE_KERNEL = 76 + 120
 BYTES_LOOP = 436
 

@@ -153,7 +153,7 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out);
 int ptx_owned_pixels(const ptx_tracer *t);              /* pixels this tracer generates (tile split)        */
 void *ptx_stream(ptx_tracer *t);
 /* Optional per-kernel device timing (hipEvents on the tracer's stream around every launch while on).
- * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_scan, 3 = k_move.
+ * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = unused, 3 = k_move.
  * ptx_get_kernel_times returns the sums since it was last called and clears them. */
 int ptx_set_kernel_timing(ptx_tracer *t, int on);
 int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_by_kind[4]);

@@ -341,7 +341,7 @@ class Tracer:
         ms = np.zeros(4, np.float64)
         n = np.zeros(4, np.int64)
         _check(self.lib.ptx_get_kernel_times(self.h, _ptr(ms), _ptr(n)), "ptx_get_kernel_times")
-        names = ("k_bounce<first>", "k_bounce", "k_scan", "k_move")
+        names = ("k_bounce<first>", "k_bounce", "unused", "k_move")
         return {nm: (float(ms[k]), int(n[k])) for k, nm in enumerate(names)}
 
     def owned_pixels(self):

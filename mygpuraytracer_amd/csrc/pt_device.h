@@ -202,9 +202,16 @@ struct DScene {
     const DGeom *__restrict__ geoms;
     const DMaterial *__restrict__ mats;
     const float *__restrict__ faces;    // 15 floats per face: 3 x (pos xyz, uv)
+    const float *__restrict__ tri9;     // 9 floats per face: v0, e1 = v1 - v0, e2 = v2 - v0 (the subtractions the
+                                        // triangle test starts with, done once at upload: same IEEE results)
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
+    int32_t tri_lds;                    // != 0: the kernel has staged tri9 at the start of its dynamic LDS (pt_lds)
+    int32_t ntri;
 };
+
+// dynamic LDS of the kernels that use this header: [tri9 copy when sc.tri_lds][per-tile ranking histogram]
+extern __shared__ __attribute__((aligned(16))) int32_t pt_lds[];
 
 enum { G_SPHERE = 0, G_CUBE = 1, G_TRIANGLE = 2, G_OBJ = 3 };
 
@@ -217,14 +224,25 @@ PT_DEV vec3 getPointOnRay(Ray r, float t) {
     return add(r.o, V3(tt * nd.x, tt * nd.y, tt * nd.z));
 }
 
-// boxIntersectionTest, src/intersections.h:48-90.  Returns t (world distance) or -1.
-PT_DEV float boxIntersectionTest(const DGeom &box, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+// What a geom test leaves behind for the normal, which only the nearest hit needs (computeIntersections keeps the
+// normal of the winner only, src/pathtrace.cu:318-324): evaluating it after the loop is the same arithmetic, once.
+struct Cand {
+    int32_t axis; float sgn;     // cube: which component of the zero-initialised glm::vec3 n is +-1
+    vec3 objP;                   // sphere: object-space hit point
+    vec3 point;                  // cube / sphere: world-space hit point (only the per-function entry point reads it)
+    bool outside;
+    int32_t face;                // mesh: nearest face (index inside the geom)
+    float u, v;                  // mesh: interpolated texcoord
+};
+
+// boxIntersectionTest without its normal, src/intersections.h:48-85,87.  Returns t (world distance) or -1.
+PT_DEV float boxTestCore(const DGeom &box, Ray r, Cand &c) {
     Ray q;
     q.o = multiplyMV(box.inv, r.o, 1.0f);
     q.d = normalize(multiplyMV(box.inv, r.d, 0.0f));
     float tmin = -1e38f, tmax = 1e38f;
-    int tmin_axis = -1, tmax_axis = -1;      // which component of the zero-initialised glm::vec3 n is set
-    float tmin_s = 0.f, tmax_s = 0.f;        // and its value (+1 / -1)
+    int tmin_axis = -1, tmax_axis = -1;
+    float tmin_s = 0.f, tmax_s = 0.f;
     const float qo[3] = {q.o.x, q.o.y, q.o.z};
     const float qd[3] = {q.d.x, q.d.y, q.d.z};
 #pragma unroll
@@ -238,18 +256,22 @@ PT_DEV float boxIntersectionTest(const DGeom &box, Ray r, vec3 &point, vec3 &nor
         if (tb < tmax) { tmax = tb; tmax_axis = xyz; tmax_s = ns; }
     }
     if (tmax >= tmin && tmax > 0) {
-        outside = true;
-        if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; outside = false; }
-        point = multiplyMV(box.xf, getPointOnRay(q, tmin), 1.0f);
-        vec3 n = V3(tmin_axis == 0 ? tmin_s : 0.f, tmin_axis == 1 ? tmin_s : 0.f, tmin_axis == 2 ? tmin_s : 0.f);
-        normal = normalize(multiplyMV(box.invT, n, 0.0f));
-        return length(sub(r.o, point));
+        c.outside = true;
+        if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; c.outside = false; }
+        c.axis = tmin_axis; c.sgn = tmin_s;
+        c.point = multiplyMV(box.xf, getPointOnRay(q, tmin), 1.0f);
+        return length(sub(r.o, c.point));
     }
     return -1.f;
 }
+// the normal of that hit, src/intersections.h:86
+PT_DEV vec3 boxNormal(const DGeom &box, const Cand &c) {
+    vec3 n = V3(c.axis == 0 ? c.sgn : 0.f, c.axis == 1 ? c.sgn : 0.f, c.axis == 2 ? c.sgn : 0.f);
+    return normalize(multiplyMV(box.invT, n, 0.0f));
+}
 
-// sphereIntersectionTest, src/intersections.h:102-144
-PT_DEV float sphereIntersectionTest(const DGeom &sphere, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+// sphereIntersectionTest without its normal, src/intersections.h:102-137,143
+PT_DEV float sphereTestCore(const DGeom &sphere, Ray r, Cand &c) {
     const float radius = .5f;
     Ray rt;
     rt.o = multiplyMV(sphere.inv, r.o, 1.0f);
@@ -266,22 +288,37 @@ PT_DEV float sphereIntersectionTest(const DGeom &sphere, Ray r, vec3 &point, vec
         return -1.f;
     } else if (t1 > 0 && t2 > 0) {
         t = fmin_glm(t1, t2);
-        outside = true;
+        c.outside = true;
     } else {
         t = fmax_glm(t1, t2);
-        outside = false;
+        c.outside = false;
     }
-    vec3 objP = getPointOnRay(rt, t);
-    point = multiplyMV(sphere.xf, objP, 1.f);
-    normal = normalize(multiplyMV(sphere.invT, objP, 0.f));
-    if (!outside) normal = neg(normal);
-    return length(sub(r.o, point));
+    c.objP = getPointOnRay(rt, t);
+    c.point = multiplyMV(sphere.xf, c.objP, 1.f);
+    return length(sub(r.o, c.point));
+}
+// src/intersections.h:138-141
+PT_DEV vec3 sphereNormal(const DGeom &sphere, const Cand &c) {
+    vec3 normal = normalize(multiplyMV(sphere.invT, c.objP, 0.f));
+    if (!c.outside) normal = neg(normal);
+    return normal;
 }
 
-// glm::intersectRayTriangle, glm/gtx/intersect.inl:37-74 (single sided: a < epsilon => miss)
-PT_DEV bool intersectRayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 v1, vec3 v2, float &bx, float &by) {
-    vec3 e1 = sub(v1, v0);
-    vec3 e2 = sub(v2, v0);
+// Texel read as the reference indexes it (src/interactions.h:172-179): nearest, no wrap.  Indices outside the
+// image (undefined behaviour in the reference) are clamped to the valid byte range.
+PT_DEV uint32_t texel(const DScene &sc, const DTex &t, int pixelID, int c) {
+    long long idx = (long long)pixelID * t.ch + c;
+    long long n = (long long)t.w * t.h * t.ch;
+    if (idx < 0) idx = 0;
+    if (idx >= n) idx = n - 1;
+    return (uint32_t)sc.texels[t.off + (uint64_t)idx];
+}
+
+PT_DEV vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
+
+// One triangle of glm::intersectRayTriangle (glm/gtx/intersect.inl:37-74, single sided: a < epsilon => miss) with
+// e1 = v1 - v0 and e2 = v2 - v0 taken from the upload-time table.
+PT_DEV bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &bx, float &by) {
     vec3 p = cross(dir, e2);
     float a = dot(e1, p);
     if (a < 1.1920928955078125e-07f) return false;     // FLT_EPSILON
@@ -298,21 +335,9 @@ PT_DEV bool intersectRayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 v1, vec3 v2,
     return bz >= 0.0f;
 }
 
-// Texel read as the reference indexes it (src/interactions.h:172-179): nearest, no wrap.  Indices outside the
-// image (undefined behaviour in the reference) are clamped to the valid byte range.
-PT_DEV uint32_t texel(const DScene &sc, const DTex &t, int pixelID, int c) {
-    long long idx = (long long)pixelID * t.ch + c;
-    long long n = (long long)t.w * t.h * t.ch;
-    if (idx < 0) idx = 0;
-    if (idx >= n) idx = n - 1;
-    return (uint32_t)sc.texels[t.off + (uint64_t)idx];
-}
-
-PT_DEV vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
-
-// meshIntersectionTest, src/intersections.h:207-282.  Returns the OBJECT-space distance, as the reference does.
-PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &geom, Ray r, vec3 &point, vec3 &normal, float &u,
-                                  float &v, bool &outside) {
+// meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space
+// distance, as the reference does.  (intersectionPoint, which the reference also fills, has no reader.)
+PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
     Ray q;
     q.o = multiplyMV(geom.inv, r.o, 1.0f);
     q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
@@ -320,32 +345,42 @@ PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &geom, Ray r, ve
     int nearest = -1;
     const float *__restrict__ faces = sc.faces + (size_t)geom.faceStart * 15;
     for (int j = 0; j < geom.faceCount; j++) {
-        const float *__restrict__ tri = faces + (size_t)j * 15;
-        vec3 p0 = ld3(tri), p1 = ld3(tri + 5), p2 = ld3(tri + 10);
+        vec3 v0, e1, e2;
+        if (sc.tri_lds) {             // broadcast ds_reads: every lane reads the same triangle
+            const float *t9 = reinterpret_cast<const float *>(pt_lds) + (size_t)(geom.faceStart + j) * 9;
+            v0 = V3(t9[0], t9[1], t9[2]); e1 = V3(t9[3], t9[4], t9[5]); e2 = V3(t9[6], t9[7], t9[8]);
+        } else {
+            const float *__restrict__ t9 = sc.tri9 + (size_t)(geom.faceStart + j) * 9;
+            v0 = ld3(t9); e1 = ld3(t9 + 3); e2 = ld3(t9 + 6);
+        }
         float b0, b1;
-        if (intersectRayTriangle(q.o, q.d, p0, p1, p2, b0, b1)) {
+        if (rayTriangle(q.o, q.d, v0, e1, e2, b0, b1)) {
+            const float *__restrict__ tri = faces + (size_t)j * 15;
+            vec3 p1 = ld3(tri + 5), p2 = ld3(tri + 10);
             float w = 1 - b0 - b1;
-            vec3 p = add(add(scale(p0, w), scale(p1, b0)), scale(p2, b1));
+            vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
             float t = length(sub(q.o, p));          // glm::distance(p, q.origin)
             if (t < tmin) {
                 tmin = t;
                 nearest = j;
-                u = (w * tri[3] + b0 * tri[8]) + b1 * tri[13];
-                v = (w * tri[4] + b0 * tri[9]) + b1 * tri[14];
+                c.u = (w * tri[3] + b0 * tri[8]) + b1 * tri[13];
+                c.v = (w * tri[4] + b0 * tri[9]) + b1 * tri[14];
             }
         }
     }
+    c.face = nearest;
     if (nearest == -1) return -1.f;
-    vec3 objP = getPointOnRay(q, tmin);
-    const float *__restrict__ tri = faces + (size_t)nearest * 15;
+    return tmin;
+}
+// geometric normal (+ optional tangent-space bump map) of the chosen face, src/intersections.h:237-279
+PT_DEV vec3 meshNormal(const DScene &sc, const DGeom &geom, const Cand &c) {
+    const float *__restrict__ tri = sc.faces + ((size_t)geom.faceStart + c.face) * 15;
     vec3 e1 = sub(ld3(tri + 5), ld3(tri));
     vec3 e2 = sub(ld3(tri + 10), ld3(tri));
     vec3 objN = normalize(cross(e1, e2));
-    point = multiplyMV(geom.xf, objP, 1.f);
-    normal = normalize(multiplyMV(geom.invT, objN, 0.f));
-    outside = dot(normal, r.d) < 0;
+    vec3 normal = normalize(multiplyMV(geom.invT, objN, 0.f));
     const DTex &bump = geom.tex[3];
-    if (geom.type == G_OBJ && bump.ch) {            // tangent-space bump map, :245-279
+    if (geom.type == G_OBJ && bump.ch) {
         float dUV1x = tri[8] - tri[3], dUV1y = tri[9] - tri[4];
         float dUV2x = tri[13] - tri[3], dUV2y = tri[14] - tri[4];
         float f = 1.0f / (dUV1x * dUV2y - dUV2x * dUV1y);
@@ -361,8 +396,8 @@ PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &geom, Ray r, ve
         vec3 T = normalize(multiplyMV(geom.xf, tangent, 0.f));
         vec3 B = normalize(multiplyMV(geom.xf, bitangent, 0.f));
         vec3 N = normal;
-        int coordU = (int)(u * bump.w);
-        int coordV = (int)(v * bump.h);
+        int coordU = (int)(c.u * bump.w);
+        int coordV = (int)(c.v * bump.h);
         int pixelID = coordV * bump.w + coordU;
         uint32_t colR = texel(sc, bump, pixelID, 0), colG = texel(sc, bump, pixelID, 1), colB = texel(sc, bump, pixelID, 2);
         vec3 tsn = normalize(V3(colR / 255.f, colG / 255.f, colB / 255.f));
@@ -372,7 +407,7 @@ PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &geom, Ray r, ve
                      T.z * tsn.x + B.z * tsn.y + N.z * tsn.z);
         normal = normalize(w3);
     }
-    return tmin;
+    return normal;
 }
 
 struct Hit {
@@ -388,29 +423,64 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
     float t_min = 3.402823466e+38f;
     h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
     int hit_geom_index = -1;
-    float tmp_u = 0.f, tmp_v = 0.f;
+    Cand best;
+    best.axis = -1; best.sgn = 0.f; best.objP = V3(0.f, 0.f, 0.f); best.outside = true; best.face = -1; best.u = best.v = 0.f;
+    float tmp_u = 0.f, tmp_v = 0.f;          // the reference's tmp_uv survives from one mesh to the next geom
     for (int i = 0; i < sc.ngeoms; i++) {
         const DGeom &geom = sc.geoms[i];
         float t = 0.f;
-        vec3 tmp_p, tmp_n = V3(0.f, 0.f, 0.f);
-        bool outside = true;
+        Cand c;
+        c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = tmp_u; c.v = tmp_v;
         bool tested = true;
-        if (geom.type == G_CUBE) t = boxIntersectionTest(geom, ray, tmp_p, tmp_n, outside);
-        else if (geom.type == G_SPHERE) t = sphereIntersectionTest(geom, ray, tmp_p, tmp_n, outside);
-        else if (geom.type == G_OBJ) t = meshIntersectionTest(sc, geom, ray, tmp_p, tmp_n, tmp_u, tmp_v, outside);
+        if (geom.type == G_CUBE) t = boxTestCore(geom, ray, c);
+        else if (geom.type == G_SPHERE) t = sphereTestCore(geom, ray, c);
+        else if (geom.type == G_OBJ) { t = meshTestCore(sc, geom, ray, c); tmp_u = c.u; tmp_v = c.v; }
         else tested = false;    // TRIANGLE has no test routine in the reference: t keeps a value that never wins
         if (tested && t > 0.0f && t_min > t) {
             t_min = t;
             hit_geom_index = i;
-            h.n = tmp_n;
-            h.u = tmp_u; h.v = tmp_v;
+            best = c;
         }
     }
     if (hit_geom_index != -1) {
+        const DGeom &geom = sc.geoms[hit_geom_index];
         h.t = t_min;
         h.geom = hit_geom_index;
-        h.mat = sc.geoms[hit_geom_index].materialid;
+        h.mat = geom.materialid;
+        h.u = best.u; h.v = best.v;
+        if (geom.type == G_CUBE) h.n = boxNormal(geom, best);
+        else if (geom.type == G_SPHERE) h.n = sphereNormal(geom, best);
+        else h.n = meshNormal(sc, geom, best);
     }
+}
+
+// Whole per-geom tests as the reference exposes them (used by the per-function parity entry point)
+PT_DEV float boxIntersectionTest(const DGeom &g, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+    Cand c; c.axis = -1; c.sgn = 0.f; c.outside = true;
+    float t = boxTestCore(g, r, c);
+    if (t != -1.f) { outside = c.outside; point = c.point; normal = boxNormal(g, c); }
+    return t;
+}
+PT_DEV float sphereIntersectionTest(const DGeom &g, Ray r, vec3 &point, vec3 &normal, bool &outside) {
+    Cand c; c.objP = V3(0.f, 0.f, 0.f); c.outside = true;
+    float t = sphereTestCore(g, r, c);
+    if (t != -1.f) { outside = c.outside; point = c.point; normal = sphereNormal(g, c); }
+    return t;
+}
+PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &g, Ray r, vec3 &point, vec3 &normal, float &u, float &v,
+                                  bool &outside) {
+    Cand c; c.face = -1; c.u = u; c.v = v;
+    float t = meshTestCore(sc, g, r, c);
+    u = c.u; v = c.v;
+    if (t != -1.f) {
+        Ray q;                                      // src/intersections.h:235,241 (the unused intersectionPoint)
+        q.o = multiplyMV(g.inv, r.o, 1.0f);
+        q.d = normalize(multiplyMV(g.inv, r.d, 0.0f));
+        point = multiplyMV(g.xf, getPointOnRay(q, t), 1.f);
+        normal = meshNormal(sc, g, c);
+        outside = dot(normal, r.d) < 0;
+    }
+    return t;
 }
 
 // ---- BSDF --------------------------------------------------------------------------------------------------------

@@ -4,14 +4,15 @@
 //
 //  * Streams are SoA (one fp32/int32 array per field, coalesced 256-B wave accesses), not the reference's 44-B
 //    PathSegment / 32-B ShadeableIntersection AoS records.
-//  * One bounce = one fused kernel + one stable multi-bin partition:
+//  * One bounce = one fused kernel + one stable multi-bin partition (two launches):
 //      k_bounce : shade(b-1) [src/pathtrace.cu:355-404 + interactions.h scatterRay] immediately followed by
 //                 computeIntersections(b) [:261-344] of the scattered ray, for every path still alive; bounce 0
 //                 fuses generateRayFromCamera [:206-255] instead of a shade.  Paths that end at bounce b (miss,
 //                 light, last bounce, emissive texel) add their radiance to the image right there, which is
 //                 what finalGather [:407-416] would do later (each pixel exactly once per iteration), and are
 //                 dropped -- only paths that will scatter again are stored.
-//      k_scan   : exclusive scan of the per-tile per-material counts.
+//                 Every workgroup owns a contiguous chunk of tiles and keeps running per-material counts, so a
+//                 tile's prefix = (totals of earlier workgroups) + (running count inside the chunk): no scan pass.
 //      k_move   : writes every stored path to its rank in (material descending, previous order) order.  That
 //                 single stable counting sort equals the reference's stable_partition [:541] followed by the
 //                 next bounce's stable sort_by_key by material [:518].  The rank a path WOULD have among all
@@ -82,7 +83,11 @@ struct BounceParams {
     int32_t aa, dof, sort;
     int32_t nbins, maxTiles;
     const int32_t *totals_prev;            // [nbins] stored-path totals of bounce b-1 (n_in = their sum)
-    int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]
+    int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]: prefix of the tile inside its workgroup's chunk
+    int32_t *chunk_all, *chunk_scat;       // [nbins][gridDim.x]: totals of each workgroup's chunk of tiles
+    int32_t *super_all, *super_scat;       // [nbins][nsuper]:   totals per 64 consecutive workgroups (atomics)
+    int32_t *totals_all, *totals_scat;     // [nbins] of this bounce (atomics)
+    int32_t nsuper;
     // first-bounce cache fill (iter 1, AA and DoF off): bounce-0 light hits are replayed on later iterations
     int32_t *emit_count; int32_t *emit_pix; float *emit_rgb;
 };
@@ -96,13 +101,26 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 template <bool FIRST>
 __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];     // [2][WAVES][nbins]
+    // dynamic LDS (pt_lds): [tri9 table when staged][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = p.nbins;
+    const int triWords = p.sc.tri_lds ? ((p.sc.ntri * 9 + 3) & ~3) : 0;
+    int32_t *lds = pt_lds + triWords;
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
+    int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
+    if (p.sc.tri_lds) {
+        float *t9 = reinterpret_cast<float *>(pt_lds);
+        for (int k = tid; k < p.sc.ntri * 9; k += TILE) t9[k] = p.sc.tri9[k];
+    }
+    for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
+    __syncthreads();
     const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // every workgroup owns a contiguous chunk of tiles, so that the prefix of a tile is (prefix of its chunk) +
+    // (running sum inside the chunk) and no separate scan pass over the tiles is needed
+    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
+    for (int tile = tile0; tile < tile1; tile++) {
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
         PathState ps;
@@ -192,8 +210,10 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
         for (int b = tid; b < nb; b += TILE) {
             int ca = 0, cs = 0;
             for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
-            p.counts_all[(size_t)b * p.maxTiles + tile] = ca;
-            p.counts_scat[(size_t)b * p.maxTiles + tile] = cs;
+            p.counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
+            p.counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+            run_all[b] += ca;
+            run_scat[b] += cs;
         }
         if (i < n_in) {
             p.stage.idx[i] = pending ? bin : -1;
@@ -211,59 +231,48 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
         }
         __syncthreads();
     }
-}
-
-struct ScanParams {
-    int32_t nbins, maxTiles, first, owned;
-    const int32_t *totals_prev;
-    int32_t *counts_all, *counts_scat;
-    int32_t *totals_all, *totals_scat;     // [nbins] of this bounce
-};
-
-// Exclusive scan along tiles of one (which, bin) column; grid = (nbins, 2), 1024 threads.
-__global__ __launch_bounds__(1024) void k_scan(const ScanParams p) {
-    __shared__ int32_t part[1024];
-    const int b = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
-    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev, p.nbins);
-    const int ntiles = (n_in + TILE - 1) / TILE;
-    int32_t *col = (which ? p.counts_scat : p.counts_all) + (size_t)b * p.maxTiles;
-    const int chunk = (ntiles + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(lo + chunk, ntiles);
-    int s = 0;
-    for (int k = lo; k < hi; k++) s += col[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of 1024 partials
-        int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    for (int b = tid; b < nb; b += TILE) {
+        const int ca = run_all[b], cs = run_scat[b];
+        p.chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
+        p.chunk_scat[(size_t)b * gridDim.x + blockIdx.x] = cs;
+        if (ca) { atomicAdd(&p.super_all[b * p.nsuper + (blockIdx.x >> 6)], ca); atomicAdd(&p.totals_all[b], ca); }
+        if (cs) { atomicAdd(&p.super_scat[b * p.nsuper + (blockIdx.x >> 6)], cs); atomicAdd(&p.totals_scat[b], cs); }
     }
-    int run = part[tid] - s;
-    for (int k = lo; k < hi; k++) { int c = col[k]; col[k] = run; run += c; }
-    if (tid == 1023) (which ? p.totals_scat : p.totals_all)[b] = part[1023];
 }
 
 struct MoveParams {
     PathSoA stage, out;
-    int32_t nbins, maxTiles, first, owned;
+    int32_t nbins, maxTiles, first, owned, nsuper;
     const int32_t *totals_prev;
-    const int32_t *counts_all, *counts_scat, *totals_all, *totals_scat;
+    const int32_t *counts_all, *counts_scat, *chunk_all, *chunk_scat, *super_all, *super_scat, *totals_all, *totals_scat;
 };
 
-// Stable multi-bin partition: stored path -> position base_scat[bin] + tile prefix + in-tile rank.
+// Stable multi-bin partition: stored path -> position binBase[bin] + chunkBase[bin] + prefixInChunk + rankInTile.
+// Must be launched with the same grid as the k_bounce that produced the counts (same chunking of tiles).
 __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];     // base_all[nb], base_scat[nb]
-    const int nb = p.nbins, tid = threadIdx.x;
-    int32_t *base_all = lds, *base_scat = lds + nb;
-    if (tid == 0) {
-        int a = 0, s = 0;
-        for (int b = 0; b < nb; b++) { base_all[b] = a; base_scat[b] = s; a += p.totals_all[b]; s += p.totals_scat[b]; }
+    const int nb = p.nbins, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *base_all = pt_lds, *base_scat = pt_lds + nb;          // dynamic LDS: base_all[nb], base_scat[nb]
+    // chunk base of (which, bin) = sum over earlier groups of 64 workgroups + earlier workgroups of the own group
+    const int my_super = blockIdx.x >> 6, in_super = blockIdx.x & 63;
+    for (int pr = wave; pr < 2 * nb; pr += WAVES) {
+        const int which = pr >= nb, b = which ? pr - nb : pr;
+        const int32_t *sup = (which ? p.super_scat : p.super_all) + b * p.nsuper;
+        const int32_t *chk = (which ? p.chunk_scat : p.chunk_all) + (size_t)b * gridDim.x + (size_t)my_super * 64;
+        const int32_t *tot = which ? p.totals_scat : p.totals_all;
+        int s = 0;
+        for (int k = lane; k < my_super; k += 64) s += sup[k];
+        if (lane < in_super) s += chk[lane];
+        for (int k = lane; k < b; k += 64) s += tot[k];          // bins ahead of this one (material descending)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) (which ? base_scat : base_all)[b] = s;
     }
     __syncthreads();
     const int n_in = p.first ? p.owned : sum_totals(p.totals_prev, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
+    for (int tile = tile0; tile < tile1; tile++) {
         const int i = tile * TILE + tid;
         if (i >= n_in) continue;
         const int bin = p.stage.idx[i];
@@ -442,7 +451,12 @@ struct ptx_tracer {
     int32_t *d_ibuf[3] = {nullptr, nullptr, nullptr};
     PathSoA soa[3];                                      // 0 = stream, 1 = stage, 2 = first-bounce cache
     int32_t *d_counts = nullptr;                         // [2][nbins][maxTiles]
-    int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins]
+    int32_t *d_chunk = nullptr;                          // [2][nbins][grid]
+    int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
+    int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
+    float *d_tri9 = nullptr;
+    int nsuper = 1, ntri = 0, tri_lds = 0;
+    size_t totals_bytes = 0;
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
     int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total
@@ -453,7 +467,7 @@ struct ptx_tracer {
     // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
     bool ktiming = false;
     std::vector<hipEvent_t> kev;                         // pairs (start, stop)
-    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_scan, 3 k_move
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 (unused), 3 k_move
     size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;
@@ -461,7 +475,8 @@ struct ptx_tracer {
     float *d_cap_f = nullptr;                            // the 15 float fields [cap each]
     bool cap_filled = false;
     DScene scene() const {
-        DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
+        DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
+        s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
     bool cache_active() const { return opt.cache_first_bounce && !opt.antialiasing && !opt.depth_of_field; }
@@ -485,10 +500,10 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
-    hipFree(t->d_counts); hipFree(t->d_totals); hipFree(t->d_cache_totals);
+    hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
     hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
@@ -500,13 +515,18 @@ int free_tracer(ptx_tracer *t) {
 
 int enqueue_iteration(ptx_tracer *t, int iter) {
     const int nb = t->nbins;
-    const size_t lds_bounce = sizeof(int32_t) * 2 * WAVES * nb;
+    const int triWords = t->tri_lds ? ((t->ntri * 9 + 3) & ~3) : 0;
+    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter != 1;
     const bool fill_cache = cache_on && !use_cache;
     int32_t *counts_all = t->d_counts, *counts_scat = t->d_counts + (size_t)nb * t->maxTiles;
+    int32_t *chunk_all = t->d_chunk, *chunk_scat = t->d_chunk + (size_t)nb * t->grid;
     auto totals = [&](int bounce, int which) { return t->d_totals + ((size_t)bounce * 2 + which) * nb; };
+    auto supers = [&](int bounce, int which) { return t->d_super + ((size_t)bounce * 2 + which) * nb * t->nsuper; };
+    // per-bounce totals and group totals are accumulated with atomics: clear them once per iteration
+    HIPCHECK(hipMemsetAsync(t->d_totals, 0, t->totals_bytes, t->stream));
 
     // per-kernel timing brackets (only when switched on; costs two event records per launch)
     auto kt_begin = [&](int kind) -> int {
@@ -540,7 +560,7 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
             continue;
         }
         BounceParams bp;
-        bp.sc = t->scene(); bp.cam = t->cam; bp.tm = t->tm;
+        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.cam = t->cam; bp.tm = t->tm;
         bp.in = (b == 1 && cache_on) ? t->soa[2] : t->soa[0];   // with the cache on, bounce 0 always lands in soa[2]
         bp.stage = t->soa[1];
         bp.image = t->d_image;
@@ -549,25 +569,24 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.totals_prev = first ? nullptr : totals(b - 1, 1);
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
+        bp.chunk_all = chunk_all; bp.chunk_scat = chunk_scat;
+        bp.super_all = supers(b, 0); bp.super_scat = supers(b, 1);
+        bp.totals_all = totals(b, 0); bp.totals_scat = totals(b, 1);
+        bp.nsuper = t->nsuper;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
         if (first) KT(0, hipLaunchKernelGGL(k_bounce<true>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
         else KT(1, hipLaunchKernelGGL(k_bounce<false>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
 
-        ScanParams sp;
-        sp.nbins = nb; sp.maxTiles = t->maxTiles; sp.first = first; sp.owned = t->tm.owned;
-        sp.totals_prev = bp.totals_prev;
-        sp.counts_all = counts_all; sp.counts_scat = counts_scat;
-        sp.totals_all = totals(b, 0); sp.totals_scat = totals(b, 1);
-        KT(2, hipLaunchKernelGGL(k_scan, dim3(nb, 2), dim3(1024), 0, t->stream, sp));
-
         if (b + 1 < t->traceDepth) {
             MoveParams mp;
             mp.stage = t->soa[1];
             mp.out = (first && cache_on) ? t->soa[2] : t->soa[0];
-            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned;
+            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper;
             mp.totals_prev = bp.totals_prev;
             mp.counts_all = counts_all; mp.counts_scat = counts_scat;
+            mp.chunk_all = chunk_all; mp.chunk_scat = chunk_scat;
+            mp.super_all = supers(b, 0); mp.super_scat = supers(b, 1);
             mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
             KT(3, hipLaunchKernelGGL(k_move, dim3(t->grid), dim3(TILE), lds_move, t->stream, mp));
         }
@@ -689,6 +708,15 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             }
         }
     }
+    // upload-time triangle table for the intersection loop: v0, e1 = v1 - v0, e2 = v2 - v0
+    t->ntri = (int)(hfaces.size() / 15);
+    std::vector<float> htri9((size_t)std::max(t->ntri, 1) * 9, 0.f);
+    for (int j = 0; j < t->ntri; j++) {
+        const float *f = &hfaces[(size_t)j * 15];
+        float *o = &htri9[(size_t)j * 9];
+        for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
+    }
+    t->tri_lds = (t->ntri > 0 && (size_t)t->ntri * 36 <= 32768) ? 1 : 0;     // <= 32 KB keeps 4 workgroups per CU
     if (hfaces.empty()) hfaces.resize(15, 0.f);
     if (htex.empty()) htex.resize(16, 0);
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
@@ -700,6 +728,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemcpy(t->d_mats, hm.data(), sizeof(DMaterial) * hm.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_faces, sizeof(float) * hfaces.size()));
     HC(hipMemcpy(t->d_faces, hfaces.data(), sizeof(float) * hfaces.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_tri9, sizeof(float) * htri9.size()));
+    HC(hipMemcpy(t->d_tri9, htri9.data(), sizeof(float) * htri9.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_texels, htex.size()));
     HC(hipMemcpy(t->d_texels, htex.data(), htex.size(), hipMemcpyHostToDevice));
 
@@ -717,8 +747,12 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], (size_t)t->cap);
     }
     HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles));
-    HC(hipMalloc(&t->d_totals, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces));
-    HC(hipMemset(t->d_totals, 0, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces));
+    t->nsuper = (t->grid + 63) / 64;
+    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid));
+    t->totals_bytes = sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces * (1 + (size_t)t->nsuper);
+    HC(hipMalloc(&t->d_totals, t->totals_bytes));
+    HC(hipMemset(t->d_totals, 0, t->totals_bytes));
+    t->d_super = t->d_totals + 2 * (size_t)t->nbins * t->maxBounces;
     HC(hipMalloc(&t->d_cache_totals, sizeof(int32_t) * 2 * (size_t)t->nbins));
     HC(hipMalloc(&t->d_emit_count, sizeof(int32_t)));
     HC(hipMemset(t->d_emit_count, 0, sizeof(int32_t)));
