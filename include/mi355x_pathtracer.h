@@ -88,7 +88,9 @@ typedef struct ptx_options {
     int32_t bounding_box;        /* BOUNDING_BOX 0 (accepted, must be 0) */
     int32_t tile_rows, tile_rank, tile_world;   /* 0,0,1 = whole frame */
     int32_t device;              /* HIP device ordinal, -1 = current device */
-    int32_t reserved[7];
+    int32_t batch;               /* iterations traced per launch set by ptx_render (independent streams, results
+                                    identical to one at a time); 0 = choose from the tile size */
+    int32_t reserved[6];
 } ptx_options;
 
 typedef struct ptx_stats {

@@ -61,6 +61,13 @@ struct PathSoA {
 };
 constexpr int SOA_FLOATS = 15, SOA_INTS = 4;
 
+__device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
+    s.ox += off; s.oy += off; s.oz += off; s.dx += off; s.dy += off; s.dz += off; s.cr += off; s.cg += off; s.cb += off;
+    s.t += off; s.nx += off; s.ny += off; s.nz += off; s.u += off; s.v += off;
+    s.pix += off; s.mg += off; s.idx += off; s.rank += off;
+    return s;
+}
+
 struct TileMap {           // which pixels this device owns (row blocks round-robin over tile_world)
     int32_t W, H, tile_rows, tile_rank, tile_world, owned;
 };
@@ -88,6 +95,11 @@ struct BounceParams {
     int32_t *super_all, *super_scat;       // [nbins][nsuper]:   totals per 64 consecutive workgroups (atomics)
     int32_t *totals_all, *totals_scat;     // [nbins] of this bounce (atomics)
     int32_t nsuper;
+    // batching: blockIdx.y = segment = one iteration of the batch (iteration p.iter + segment), each an independent
+    // stream with its own buffers at these strides (in elements)
+    size_t seg_in, seg_stage, seg_counts, seg_chunk, seg_totals, seg_part;
+    float *part;                           // != NULL: every ending path STORES its radiance to part[segment][pix]
+                                           // (k_gather adds the segments to the image in iteration order)
     // first-bounce cache fill (iter 1, AA and DoF off): bounce-0 light hits are replayed on later iterations
     int32_t *emit_count; int32_t *emit_pix; float *emit_rgb;
 };
@@ -96,6 +108,19 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
     int s = 0;
     for (int b = 0; b < n; b++) s += t[b];
     return s;
+}
+
+// A path that ends adds its radiance to its pixel (finalGather, src/pathtrace.cu:407-416).  Each pixel ends exactly
+// once per iteration, so this is a plain read-modify-write, or -- when several iterations are in flight as
+// segments of one launch -- a plain store into that iteration's buffer.
+__device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3 c) {
+    if (part) {
+        float *px = part + (size_t)pix * 3;
+        px[0] = c.x; px[1] = c.y; px[2] = c.z;
+    } else {
+        float *px = image + (size_t)pix * 3;
+        px[0] += c.x; px[1] += c.y; px[2] += c.z;
+    }
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
@@ -114,7 +139,15 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
     }
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
     __syncthreads();
-    const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev, nb);
+    const int seg = blockIdx.y;
+    const int iter = p.iter + seg;
+    const PathSoA in = soa_offset(p.in, p.seg_in * seg), stage = soa_offset(p.stage, p.seg_stage * seg);
+    int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
+    int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
+    int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
+    int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
+    float *part = p.part ? p.part + p.seg_part * seg : nullptr;
+    const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev + p.seg_totals * seg, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
     // every workgroup owns a contiguous chunk of tiles, so that the prefix of a tile is (prefix of its chunk) +
     // (running sum inside the chunk) and no separate scan pass over the tiles is needed
@@ -131,25 +164,24 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
                 int x, y;
                 owned_pixel(p.tm, i, x, y);
                 pix = x + y * p.cam.resx;
-                generateRay(p.cam, p.iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
+                generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                ps.o = V3(p.in.ox[i], p.in.oy[i], p.in.oz[i]);
-                ps.d = V3(p.in.dx[i], p.in.dy[i], p.in.dz[i]);
-                ps.color = V3(p.in.cr[i], p.in.cg[i], p.in.cb[i]);
-                pix = p.in.pix[i];
+                ps.o = V3(in.ox[i], in.oy[i], in.oz[i]);
+                ps.d = V3(in.dx[i], in.dy[i], in.dz[i]);
+                ps.color = V3(in.cr[i], in.cg[i], in.cb[i]);
+                pix = in.pix[i];
                 Hit h;
-                h.t = p.in.t[i];
-                h.n = V3(p.in.nx[i], p.in.ny[i], p.in.nz[i]);
-                h.u = p.in.u[i]; h.v = p.in.v[i];
-                int mg = p.in.mg[i];
+                h.t = in.t[i];
+                h.n = V3(in.nx[i], in.ny[i], in.nz[i]);
+                h.u = in.u[i]; h.v = in.v[i];
+                int mg = in.mg[i];
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
-                Rng rng; rng.seed(p.iter, p.in.idx[i], 0);
+                Rng rng; rng.seed(iter, in.idx[i], 0);
                 vec3 intersect = add(ps.o, scale(ps.d, h.t));
                 bool ended = scatterRay(p.sc, ps, intersect, h, p.sc.mats[h.mat], rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
-                    float *px = p.image + (size_t)pix * 3;
-                    px[0] += ps.color.x; px[1] += ps.color.y; px[2] += ps.color.z;
+                    deposit(p.image, part, pix, ps.color);
                     alive = false;
                 }
             }
@@ -167,8 +199,7 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
                 const DMaterial &m = p.sc.mats[hit.mat];
                 if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
                     vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-                    float *px = p.image + (size_t)pix * 3;
-                    px[0] += c.x; px[1] += c.y; px[2] += c.z;
+                    deposit(p.image, part, pix, c);
                     if (FIRST && p.emit_count) {
                         int k = atomicAdd(p.emit_count, 1);
                         p.emit_pix[k] = pix;
@@ -177,6 +208,12 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
                 } else if (p.traceDepth - p.bounce != 1) {         // :387-390 (last bounce => black)
                     pending = true;
                 }
+            }
+            // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
+            // in batched mode the path's slot of the per-iteration buffer must still be written
+            if (part && !pending && !(hit.t > 0.0f && p.sc.mats[hit.mat].emittance > 0.0f)) {
+                float *px = part + (size_t)pix * 3;
+                px[0] = 0.f; px[1] = 0.f; px[2] = 0.f;
             }
         }
         // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
@@ -210,33 +247,33 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
         for (int b = tid; b < nb; b += TILE) {
             int ca = 0, cs = 0;
             for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
-            p.counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
-            p.counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+            counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
+            counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
             run_all[b] += ca;
             run_scat[b] += cs;
         }
         if (i < n_in) {
-            p.stage.idx[i] = pending ? bin : -1;
+            stage.idx[i] = pending ? bin : -1;
             if (pending) {
-                p.stage.rank[i] = r_all | (r_scat << 16);
-                p.stage.ox[i] = ps.o.x; p.stage.oy[i] = ps.o.y; p.stage.oz[i] = ps.o.z;
-                p.stage.dx[i] = ps.d.x; p.stage.dy[i] = ps.d.y; p.stage.dz[i] = ps.d.z;
-                p.stage.cr[i] = ps.color.x; p.stage.cg[i] = ps.color.y; p.stage.cb[i] = ps.color.z;
-                p.stage.t[i] = hit.t;
-                p.stage.nx[i] = hit.n.x; p.stage.ny[i] = hit.n.y; p.stage.nz[i] = hit.n.z;
-                p.stage.u[i] = hit.u; p.stage.v[i] = hit.v;
-                p.stage.pix[i] = pix;
-                p.stage.mg[i] = hit.mat | (hit.geom << 16);
+                stage.rank[i] = r_all | (r_scat << 16);
+                stage.ox[i] = ps.o.x; stage.oy[i] = ps.o.y; stage.oz[i] = ps.o.z;
+                stage.dx[i] = ps.d.x; stage.dy[i] = ps.d.y; stage.dz[i] = ps.d.z;
+                stage.cr[i] = ps.color.x; stage.cg[i] = ps.color.y; stage.cb[i] = ps.color.z;
+                stage.t[i] = hit.t;
+                stage.nx[i] = hit.n.x; stage.ny[i] = hit.n.y; stage.nz[i] = hit.n.z;
+                stage.u[i] = hit.u; stage.v[i] = hit.v;
+                stage.pix[i] = pix;
+                stage.mg[i] = hit.mat | (hit.geom << 16);
             }
         }
         __syncthreads();
     }
     for (int b = tid; b < nb; b += TILE) {
         const int ca = run_all[b], cs = run_scat[b];
-        p.chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
-        p.chunk_scat[(size_t)b * gridDim.x + blockIdx.x] = cs;
-        if (ca) { atomicAdd(&p.super_all[b * p.nsuper + (blockIdx.x >> 6)], ca); atomicAdd(&p.totals_all[b], ca); }
-        if (cs) { atomicAdd(&p.super_scat[b * p.nsuper + (blockIdx.x >> 6)], cs); atomicAdd(&p.totals_scat[b], cs); }
+        chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
+        chunk_scat[(size_t)b * gridDim.x + blockIdx.x] = cs;
+        if (ca) { atomicAdd(&super_all[b * p.nsuper + (blockIdx.x >> 6)], ca); atomicAdd(&totals_all[b], ca); }
+        if (cs) { atomicAdd(&super_scat[b * p.nsuper + (blockIdx.x >> 6)], cs); atomicAdd(&totals_scat[b], cs); }
     }
 }
 
@@ -245,6 +282,7 @@ struct MoveParams {
     int32_t nbins, maxTiles, first, owned, nsuper;
     const int32_t *totals_prev;
     const int32_t *counts_all, *counts_scat, *chunk_all, *chunk_scat, *super_all, *super_scat, *totals_all, *totals_scat;
+    size_t seg_stage, seg_out, seg_counts, seg_chunk, seg_totals;      // per-segment strides, as in BounceParams
 };
 
 // Stable multi-bin partition: stored path -> position binBase[bin] + chunkBase[bin] + prefixInChunk + rankInTile.
@@ -252,13 +290,24 @@ struct MoveParams {
 __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
     const int nb = p.nbins, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *base_all = pt_lds, *base_scat = pt_lds + nb;          // dynamic LDS: base_all[nb], base_scat[nb]
+    const int seg = blockIdx.y;
+    const PathSoA stage = soa_offset(p.stage, p.seg_stage * seg), out = soa_offset(p.out, p.seg_out * seg);
+    const int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
+    const int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
+    const int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
+    const int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
+    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev + p.seg_totals * seg, nb);
+    const int ntiles = (n_in + TILE - 1) / TILE;
+    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
+    if (tile0 >= tile1) return;                                    // nothing to move for this workgroup
     // chunk base of (which, bin) = sum over earlier groups of 64 workgroups + earlier workgroups of the own group
     const int my_super = blockIdx.x >> 6, in_super = blockIdx.x & 63;
     for (int pr = wave; pr < 2 * nb; pr += WAVES) {
         const int which = pr >= nb, b = which ? pr - nb : pr;
-        const int32_t *sup = (which ? p.super_scat : p.super_all) + b * p.nsuper;
-        const int32_t *chk = (which ? p.chunk_scat : p.chunk_all) + (size_t)b * gridDim.x + (size_t)my_super * 64;
-        const int32_t *tot = which ? p.totals_scat : p.totals_all;
+        const int32_t *sup = (which ? super_scat : super_all) + b * p.nsuper;
+        const int32_t *chk = (which ? chunk_scat : chunk_all) + (size_t)b * gridDim.x + (size_t)my_super * 64;
+        const int32_t *tot = which ? totals_scat : totals_all;
         int s = 0;
         for (int k = lane; k < my_super; k += 64) s += sup[k];
         if (lane < in_super) s += chk[lane];
@@ -268,27 +317,23 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
         if (lane == 0) (which ? base_scat : base_all)[b] = s;
     }
     __syncthreads();
-    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev, nb);
-    const int ntiles = (n_in + TILE - 1) / TILE;
-    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
     for (int tile = tile0; tile < tile1; tile++) {
         const int i = tile * TILE + tid;
         if (i >= n_in) continue;
-        const int bin = p.stage.idx[i];
+        const int bin = stage.idx[i];
         if (bin < 0) continue;
-        const int r = p.stage.rank[i];
-        const int idx = base_all[bin] + p.counts_all[(size_t)bin * p.maxTiles + tile] + (r & 0xffff);
-        const int pos = base_scat[bin] + p.counts_scat[(size_t)bin * p.maxTiles + tile] + (r >> 16);
-        p.out.ox[pos] = p.stage.ox[i]; p.out.oy[pos] = p.stage.oy[i]; p.out.oz[pos] = p.stage.oz[i];
-        p.out.dx[pos] = p.stage.dx[i]; p.out.dy[pos] = p.stage.dy[i]; p.out.dz[pos] = p.stage.dz[i];
-        p.out.cr[pos] = p.stage.cr[i]; p.out.cg[pos] = p.stage.cg[i]; p.out.cb[pos] = p.stage.cb[i];
-        p.out.t[pos] = p.stage.t[i];
-        p.out.nx[pos] = p.stage.nx[i]; p.out.ny[pos] = p.stage.ny[i]; p.out.nz[pos] = p.stage.nz[i];
-        p.out.u[pos] = p.stage.u[i]; p.out.v[pos] = p.stage.v[i];
-        p.out.pix[pos] = p.stage.pix[i];
-        p.out.mg[pos] = p.stage.mg[i];
-        p.out.idx[pos] = idx;
+        const int r = stage.rank[i];
+        const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + (r & 0xffff);
+        const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + (r >> 16);
+        out.ox[pos] = stage.ox[i]; out.oy[pos] = stage.oy[i]; out.oz[pos] = stage.oz[i];
+        out.dx[pos] = stage.dx[i]; out.dy[pos] = stage.dy[i]; out.dz[pos] = stage.dz[i];
+        out.cr[pos] = stage.cr[i]; out.cg[pos] = stage.cg[i]; out.cb[pos] = stage.cb[i];
+        out.t[pos] = stage.t[i];
+        out.nx[pos] = stage.nx[i]; out.ny[pos] = stage.ny[i]; out.nz[pos] = stage.nz[i];
+        out.u[pos] = stage.u[i]; out.v[pos] = stage.v[i];
+        out.pix[pos] = stage.pix[i];
+        out.mg[pos] = stage.mg[i];
+        out.idx[pos] = idx;
     }
 }
 
@@ -301,18 +346,35 @@ __global__ void k_replay_emission(const int32_t *count, const int32_t *pix, cons
     }
 }
 
+// batched mode: image[pix] += part[0][pix]; += part[1][pix]; ... in iteration order, over the pixels this device owns
+__global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const float *part, float *image) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tm.owned; i += gridDim.x * blockDim.x) {
+        int x, y;
+        owned_pixel(tm, i, x, y);
+        const size_t o = ((size_t)x + (size_t)y * resx) * 3;
+        float r = image[o], g = image[o + 1], b = image[o + 2];
+        for (int s = 0; s < nseg; s++) {
+            const float *ps = part + seg_part * s + o;
+            r += ps[0]; g += ps[1]; b += ps[2];
+        }
+        image[o] = r; image[o + 1] = g; image[o + 2] = b;
+    }
+}
+
 // per-iteration statistics: rays entering the intersect stage of each bounce = sum of totals_all[bounce]
 // (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced)
-__global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int64_t *last, int64_t *total) {
+__global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int nseg, size_t seg_totals,
+                        int64_t *last, int64_t *total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         int64_t sum = 0;
-        for (int b = 0; b < nbounces; b++) {
-            int64_t s = 0;
-            if (!(b == 0 && skip_first))
-                for (int k = 0; k < nbins; k++) s += totals[(size_t)b * stride + k];
-            if (b < 64) last[b] = s;
-            sum += s;
-        }
+        for (int sg = 0; sg < nseg; sg++)
+            for (int b = 0; b < nbounces; b++) {
+                int64_t s = 0;
+                if (!(b == 0 && skip_first))
+                    for (int k = 0; k < nbins; k++) s += totals[seg_totals * sg + (size_t)b * stride + k];
+                if (b < 64) last[b] = s;                 // per-bounce counts of the last iteration of the batch
+                sum += s;
+            }
         *total += sum;
     }
 }
@@ -456,7 +518,9 @@ struct ptx_tracer {
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr;
     int nsuper = 1, ntri = 0, tri_lds = 0;
-    size_t totals_bytes = 0;
+    size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
+    int kmax = 1;                                        // iterations per launch set (segments)
+    float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
     int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total
@@ -484,10 +548,11 @@ struct ptx_tracer {
 
 namespace {
 
-void carve(PathSoA &s, float *f, int32_t *i, size_t cap) {
+// field arrays of `stride` elements each (stride = segments x cap: segment s of a field starts at s*cap)
+void carve(PathSoA &s, float *f, int32_t *i, size_t stride) {
     float **fp[SOA_FLOATS] = {&s.ox, &s.oy, &s.oz, &s.dx, &s.dy, &s.dz, &s.cr, &s.cg, &s.cb, &s.t, &s.nx, &s.ny, &s.nz, &s.u, &s.v};
-    for (int k = 0; k < SOA_FLOATS; k++) *fp[k] = f + (size_t)k * cap;
-    s.pix = i; s.mg = i + cap; s.idx = i + 2 * cap; s.rank = i + 3 * cap;
+    for (int k = 0; k < SOA_FLOATS; k++) *fp[k] = f + (size_t)k * stride;
+    s.pix = i; s.mg = i + stride; s.idx = i + 2 * stride; s.rank = i + 3 * stride;
 }
 
 void camera_to_device(const ptx_camera &c, DCamera &d) {
@@ -504,7 +569,7 @@ int free_tracer(ptx_tracer *t) {
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
-    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
@@ -513,20 +578,31 @@ int free_tracer(ptx_tracer *t) {
     return PTX_OK;
 }
 
-int enqueue_iteration(ptx_tracer *t, int iter) {
+// Enqueues K consecutive iterations (iter_first .. iter_first+K-1) as K segments of every launch: blockIdx.y picks
+// the segment, each segment is an independent stream with its own buffers, so the launches carry K times the work
+// (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
+int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
     const int triWords = t->tri_lds ? ((t->ntri * 9 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
-    const bool use_cache = cache_on && t->cache_valid && iter != 1;
+    const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
     const bool fill_cache = cache_on && !use_cache;
+    const bool batched = K > 1;                      // ending paths store into per-iteration buffers, k_gather sums them
+    int gx = t->grid / K;                            // workgroups per segment
+    if (gx < 64) gx = 64;
+    if (gx > t->maxTiles) gx = t->maxTiles;
+    if (gx > t->grid) gx = t->grid;
+    if (gx < 1) gx = 1;
+    const int nsuper = (gx + 63) / 64;
+    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * (size_t)nb * t->grid, seg_totals = t->seg_totals;
     int32_t *counts_all = t->d_counts, *counts_scat = t->d_counts + (size_t)nb * t->maxTiles;
-    int32_t *chunk_all = t->d_chunk, *chunk_scat = t->d_chunk + (size_t)nb * t->grid;
+    int32_t *chunk_all = t->d_chunk, *chunk_scat = t->d_chunk + (size_t)nb * gx;
     auto totals = [&](int bounce, int which) { return t->d_totals + ((size_t)bounce * 2 + which) * nb; };
     auto supers = [&](int bounce, int which) { return t->d_super + ((size_t)bounce * 2 + which) * nb * t->nsuper; };
-    // per-bounce totals and group totals are accumulated with atomics: clear them once per iteration
-    HIPCHECK(hipMemsetAsync(t->d_totals, 0, t->totals_bytes, t->stream));
+    // per-bounce totals and group totals are accumulated with atomics: clear them once per batch
+    HIPCHECK(hipMemsetAsync(t->d_totals, 0, sizeof(int32_t) * seg_totals * (size_t)K, t->stream));
 
     // per-kernel timing brackets (only when switched on; costs two event records per launch)
     auto kt_begin = [&](int kind) -> int {
@@ -561,10 +637,11 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
         }
         BounceParams bp;
         bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.cam = t->cam; bp.tm = t->tm;
-        bp.in = (b == 1 && cache_on) ? t->soa[2] : t->soa[0];   // with the cache on, bounce 0 always lands in soa[2]
+        const bool from_cache = (b == 1 && cache_on);           // with the cache on, bounce 0 always lands in soa[2]
+        bp.in = from_cache ? t->soa[2] : t->soa[0];
         bp.stage = t->soa[1];
         bp.image = t->d_image;
-        bp.iter = iter; bp.traceDepth = t->traceDepth; bp.bounce = b;
+        bp.iter = iter_first; bp.traceDepth = t->traceDepth; bp.bounce = b;
         bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.totals_prev = first ? nullptr : totals(b - 1, 1);
@@ -573,42 +650,55 @@ int enqueue_iteration(ptx_tracer *t, int iter) {
         bp.super_all = supers(b, 0); bp.super_scat = supers(b, 1);
         bp.totals_all = totals(b, 0); bp.totals_scat = totals(b, 1);
         bp.nsuper = t->nsuper;
+        bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = (size_t)t->cap;
+        bp.seg_counts = seg_counts; bp.seg_chunk = seg_chunk; bp.seg_totals = seg_totals;
+        bp.part = batched ? t->d_part : nullptr; bp.seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
-        if (first) KT(0, hipLaunchKernelGGL(k_bounce<true>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
-        else KT(1, hipLaunchKernelGGL(k_bounce<false>, dim3(t->grid), dim3(TILE), lds_bounce, t->stream, bp));
+        if (first) KT(0, hipLaunchKernelGGL(k_bounce<true>, dim3(gx, K), dim3(TILE), lds_bounce, t->stream, bp));
+        else KT(1, hipLaunchKernelGGL(k_bounce<false>, dim3(gx, K), dim3(TILE), lds_bounce, t->stream, bp));
 
         if (b + 1 < t->traceDepth) {
             MoveParams mp;
             mp.stage = t->soa[1];
-            mp.out = (first && cache_on) ? t->soa[2] : t->soa[0];
+            const bool to_cache = (first && cache_on);
+            mp.out = to_cache ? t->soa[2] : t->soa[0];
             mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper;
             mp.totals_prev = bp.totals_prev;
             mp.counts_all = counts_all; mp.counts_scat = counts_scat;
             mp.chunk_all = chunk_all; mp.chunk_scat = chunk_scat;
             mp.super_all = supers(b, 0); mp.super_scat = supers(b, 1);
             mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
-            KT(3, hipLaunchKernelGGL(k_move, dim3(t->grid), dim3(TILE), lds_move, t->stream, mp));
+            mp.seg_stage = (size_t)t->cap; mp.seg_out = to_cache ? 0 : (size_t)t->cap;
+            mp.seg_counts = seg_counts; mp.seg_chunk = seg_chunk; mp.seg_totals = seg_totals;
+            KT(3, hipLaunchKernelGGL(k_move, dim3(gx, K), dim3(TILE), lds_move, t->stream, mp));
         }
         if (first && fill_cache) {
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, t->stream));
             t->cache_valid = true;
         }
-        if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {
+        if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
             const PathSoA &src = (first && cache_on) ? t->soa[2] : t->soa[0];
             size_t cb = sizeof(int32_t) * (size_t)t->cap;
             HIPCHECK(hipMemcpyAsync(t->d_cap, src.pix, cb, hipMemcpyDeviceToDevice, t->stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx, cb, hipMemcpyDeviceToDevice, t->stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg, cb, hipMemcpyDeviceToDevice, t->stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, t->stream));
-            HIPCHECK(hipMemcpyAsync(t->d_cap_f, src.ox, sizeof(float) * SOA_FLOATS * (size_t)t->cap, hipMemcpyDeviceToDevice, t->stream));
+            const size_t fstride = (first && cache_on) ? (size_t)t->cap : t->field_stride;
+            for (int f = 0; f < SOA_FLOATS; f++)
+                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.ox + (size_t)f * fstride,
+                                        sizeof(float) * (size_t)t->cap, hipMemcpyDeviceToDevice, t->stream));
             t->cap_filled = true;
         }
     }
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, t->d_stats,
-                       t->d_stats + 64);
+    if (batched)
+        hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, K,
+                           3 * (size_t)t->cam.resx * t->cam.resy, t->d_part, t->d_image);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, K,
+                       seg_totals, t->d_stats, t->d_stats + 64);
     HIPCHECK(hipGetLastError());
-    t->iterations++;
+    t->iterations += K;
+    (void)nsuper;
     return PTX_OK;
 }
 
@@ -628,7 +718,7 @@ int ptx_device_count(void) {
 void ptx_default_options(ptx_options *o) {
     memset(o, 0, sizeof *o);
     o->depth_of_field = 0; o->cache_first_bounce = 1; o->sort_by_material = 1; o->antialiasing = 1; o->bounding_box = 0;
-    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1;
+    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0;
 }
 
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
@@ -740,16 +830,27 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMemset(t->d_image, 0, sizeof(float) * 3 * npix));
         t->own_image = true;
     }
+    // iterations per launch set: explicit option, or 8 (fewer for frames so large that 8 streams would not fit in
+    // ~16 GB); the first-bounce cache shares one cached stream between iterations and stays unbatched
+    int kmax = opt.batch;
+    if (kmax <= 0) kmax = (int)std::min<long long>(8, std::max<long long>(1, (16LL << 30) / (200LL * std::max(t->tm.owned, 1))));
+    if (kmax > 64) kmax = 64;
+    if (t->cache_active()) kmax = 1;
+    t->kmax = kmax;
+    t->field_stride = (size_t)kmax * t->cap;
     const int nsoa = t->cache_active() ? 3 : 2;
     for (int k = 0; k < nsoa; k++) {
-        HC(hipMalloc(&t->d_fbuf[k], sizeof(float) * SOA_FLOATS * (size_t)t->cap));
-        HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * (size_t)t->cap));
-        carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], (size_t)t->cap);
+        const size_t stride = k == 2 ? (size_t)t->cap : t->field_stride;
+        HC(hipMalloc(&t->d_fbuf[k], sizeof(float) * SOA_FLOATS * stride));
+        HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
+        carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
-    HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles));
+    if (kmax > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * (size_t)kmax));
+    HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * kmax));
     t->nsuper = (t->grid + 63) / 64;
-    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid));
-    t->totals_bytes = sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxBounces * (1 + (size_t)t->nsuper);
+    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid * kmax));
+    t->seg_totals = 2 * (size_t)t->nbins * t->maxBounces * (1 + (size_t)t->nsuper);
+    t->totals_bytes = sizeof(int32_t) * t->seg_totals * kmax;
     HC(hipMalloc(&t->d_totals, t->totals_bytes));
     HC(hipMemset(t->d_totals, 0, t->totals_bytes));
     t->d_super = t->d_totals + 2 * (size_t)t->nbins * t->maxBounces;
@@ -807,9 +908,13 @@ int ptx_render(ptx_tracer *t, int iter_first, int count) {
         t->timing_valid = false;
     }
     HIPCHECK(hipEventRecord(t->ev_start, t->stream));
-    for (int k = 0; k < count; k++) {
-        int rc = enqueue_iteration(t, iter_first + k);
+    for (int k = 0; k < count;) {
+        int K = std::min(t->kmax, count - k);
+        if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
+        if (t->cache_active() && (!t->cache_valid || iter_first + k == 1)) K = 1;
+        int rc = enqueue_batch(t, iter_first + k, K);
         if (rc != PTX_OK) return rc;
+        k += K;
     }
     HIPCHECK(hipEventRecord(t->ev_stop, t->stream));
     t->timing_valid = true;

@@ -287,3 +287,23 @@ def test_error_paths(gpu_product):
     with pytest.raises(pt.PathTracerError):
         T.set_camera(s2)                       # resolution is fixed at init, as in the reference
     T.close(); T.close()                       # pathtraceFree is idempotent
+
+
+@pytest.mark.parametrize("tile", [None, (16, 1, 4)])
+@pytest.mark.parametrize("batch", [2, 5, 8])
+def test_batched_iterations_identical(gpu_product, batch, tile):
+    """ptx_render traces several iterations per launch set as independent segments (what keeps small multi-GPU tiles
+    efficient): the accumulated image and the ray totals are bit-identical to one iteration at a time."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt"), res=(160, 120), depth=10)
+    s.apply_runcuda_camera()
+    kw = {}
+    if tile:
+        kw = dict(tile_rows=tile[0], tile_rank=tile[1], tile_world=tile[2])
+    with pt.Tracer(s, batch=1, **kw) as A, pt.Tracer(s, batch=batch, **kw) as B:
+        A.render(1, 11); B.render(1, 11)
+        a, b = A.read_image(), B.read_image()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert A.stats()["rays_total"] == B.stats()["rays_total"]
+        A.render(12, 3); B.render(12, 3)                               # a second call continues the accumulation
+        assert np.array_equal(A.read_image().view(np.uint32), B.read_image().view(np.uint32))
