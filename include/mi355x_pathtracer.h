@@ -171,9 +171,10 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
-/* fields15 (optional): 15 rows of min(n, cap) floats: ox oy oz dx dy dz cr cg cb t nx ny nz u v */
+/* fields14 (optional): 14 rows of min(n, cap) floats: px py pz (= origin + t*direction, the point that will be
+ * shaded) dx dy dz cr cg cb nx ny nz u v (u, v only meaningful when the scene has textures) */
 int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx,
-                          int32_t *material, float *fields15, int cap);
+                          int32_t *material, float *fields14, int cap);
 
 #ifdef __cplusplus
 }

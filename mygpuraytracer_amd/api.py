@@ -402,9 +402,9 @@ class Tracer:
         n = C.c_int(0)
         _check(self.lib.ptx_debug_read_stream(self.h, C.byref(n), _ptr(pix), _ptr(idx), _ptr(mat), None, 0), "ptx_debug_read_stream")
         m = n.value
-        fields = np.zeros((15, max(m, 1)), np.float32)
+        fields = np.zeros((14, max(m, 1)), np.float32)
         _check(self.lib.ptx_debug_read_stream(self.h, C.byref(n), _ptr(pix), _ptr(idx), _ptr(mat), _ptr(fields), m), "ptx_debug_read_stream")
-        names = ("ox", "oy", "oz", "dx", "dy", "dz", "cr", "cg", "cb", "t", "nx", "ny", "nz", "u", "v")
+        names = ("px", "py", "pz", "dx", "dy", "dz", "cr", "cg", "cb", "nx", "ny", "nz", "u", "v")
         out = dict(pix=pix[:m].copy(), idx=idx[:m].copy(), mat=mat[:m].copy())
         for k, nm in enumerate(names):
             out[nm] = fields[k, :m].copy()

@@ -3,7 +3,7 @@
 // Replaces the device side of the reference's src/pathtrace.cu.  Design (see DESIGN.md for the full account):
 //
 //  * Streams are SoA (one fp32/int32 array per field, coalesced 256-B wave accesses), not the reference's 44-B
-//    PathSegment / 32-B ShadeableIntersection AoS records.
+//    PathSegment / 32-B ShadeableIntersection AoS records: 15 words per stored path (17 with texcoords).
 //  * One bounce = one fused kernel + one stable multi-bin partition (two launches):
 //      k_bounce : shade(b-1) [src/pathtrace.cu:355-404 + interactions.h scatterRay] immediately followed by
 //                 computeIntersections(b) [:261-344] of the scattered ray, for every path still alive; bounce 0
@@ -52,19 +52,22 @@ constexpr int WAVES = TILE / 64;
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
 struct PathSoA {
-    float *ox, *oy, *oz, *dx, *dy, *dz, *cr, *cg, *cb;   // ray + throughput colour
-    float *t, *nx, *ny, *nz, *u, *v;                     // pending intersection
+    float *px, *py, *pz;                                 // shading point = origin + t * direction (src/pathtrace.cu:392)
+    float *dx, *dy, *dz, *cr, *cg, *cb;                  // incoming direction, throughput colour
+    float *nx, *ny, *nz, *u, *v;                         // pending intersection: normal, texcoord (u, v only if textured)
     int32_t *pix;                                        // pixelIndex (global, x + y*W)
     int32_t *mg;                                         // materialId | geomId << 16
-    int32_t *idx;                                        // stream: RNG stream index; stage: bin or -1
-    int32_t *rank;                                       // stage only: rank among all | rank among stored << 16
+    int32_t *idx;                                        // stream: RNG stream index; stage: key (see stage_key) or -1
 };
-constexpr int SOA_FLOATS = 15, SOA_INTS = 4;
+constexpr int SOA_FLOATS = 14, SOA_INTS = 3;
+
+// stage key: bin | rank among all survivors of the tile << 16 | rank among the stored ones << 24 (ranks < 256)
+__device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << 16) | ((uint32_t)r_scat << 24)); }
 
 __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
-    s.ox += off; s.oy += off; s.oz += off; s.dx += off; s.dy += off; s.dz += off; s.cr += off; s.cg += off; s.cb += off;
-    s.t += off; s.nx += off; s.ny += off; s.nz += off; s.u += off; s.v += off;
-    s.pix += off; s.mg += off; s.idx += off; s.rank += off;
+    s.px += off; s.py += off; s.pz += off; s.dx += off; s.dy += off; s.dz += off; s.cr += off; s.cg += off; s.cb += off;
+    s.nx += off; s.ny += off; s.nz += off; s.u += off; s.v += off;
+    s.pix += off; s.mg += off; s.idx += off;
     return s;
 }
 
@@ -88,6 +91,7 @@ struct BounceParams {
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t aa, dof, sort;
+    int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     int32_t nbins, maxTiles;
     const int32_t *totals_prev;            // [nbins] stored-path totals of bounce b-1 (n_in = their sum)
     int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]: prefix of the tile inside its workgroup's chunk
@@ -125,14 +129,17 @@ __device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 template <bool FIRST>
-__global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
+__global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     // dynamic LDS (pt_lds): [tri9 table when staged][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
+    // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = p.nbins;
     const int triWords = p.sc.tri_lds ? ((p.sc.ntri * 9 + 3) & ~3) : 0;
     int32_t *lds = pt_lds + triWords;
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
+    int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
+    int32_t *rec = toff + nb + 1;                                   // [17][TILE] record transpose buffer
     if (p.sc.tri_lds) {
         float *t9 = reinterpret_cast<float *>(pt_lds);
         for (int k = tid; k < p.sc.ntri * 9; k += TILE) t9[k] = p.sc.tri9[k];
@@ -167,18 +174,18 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                ps.o = V3(in.ox[i], in.oy[i], in.oz[i]);
+                const vec3 intersect = V3(in.px[i], in.py[i], in.pz[i]);     // stored as origin + t * direction
                 ps.d = V3(in.dx[i], in.dy[i], in.dz[i]);
                 ps.color = V3(in.cr[i], in.cg[i], in.cb[i]);
                 pix = in.pix[i];
                 Hit h;
-                h.t = in.t[i];
+                h.t = 1.f;
                 h.n = V3(in.nx[i], in.ny[i], in.nz[i]);
-                h.u = in.u[i]; h.v = in.v[i];
+                h.u = 0.f; h.v = 0.f;
+                if (p.uses_uv) { h.u = in.u[i]; h.v = in.v[i]; }
                 int mg = in.mg[i];
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
                 Rng rng; rng.seed(iter, in.idx[i], 0);
-                vec3 intersect = add(ps.o, scale(ps.d, h.t));
                 bool ended = scatterRay(p.sc, ps, intersect, h, p.sc.mats[h.mat], rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
                     deposit(p.image, part, pix, ps.color);
@@ -251,19 +258,46 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
             counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
             run_all[b] += ca;
             run_scat[b] += cs;
+            tcs[b] = cs;
         }
-        if (i < n_in) {
-            stage.idx[i] = pending ? bin : -1;
-            if (pending) {
-                stage.rank[i] = r_all | (r_scat << 16);
-                stage.ox[i] = ps.o.x; stage.oy[i] = ps.o.y; stage.oz[i] = ps.o.z;
-                stage.dx[i] = ps.d.x; stage.dy[i] = ps.d.y; stage.dz[i] = ps.d.z;
-                stage.cr[i] = ps.color.x; stage.cg[i] = ps.color.y; stage.cb[i] = ps.color.z;
-                stage.t[i] = hit.t;
-                stage.nx[i] = hit.n.x; stage.ny[i] = hit.n.y; stage.nz[i] = hit.n.z;
-                stage.u[i] = hit.u; stage.v[i] = hit.v;
-                stage.pix[i] = pix;
-                stage.mg[i] = hit.mat | (hit.geom << 16);
+        __syncthreads();
+        if (tid == 0) {
+            int o = 0;
+            for (int b = 0; b < nb; b++) { toff[b] = o; o += tcs[b]; }
+            toff[nb] = o;
+        }
+        __syncthreads();
+        // Stored paths go to the stage sorted by bin inside the tile (through LDS), so that both this write and
+        // k_move's read are dense and coalesced and k_move's scattered write falls into per-bin runs.
+        if (pending) {
+            const int slot = toff[bin] + r_scat;
+            const vec3 sp = add(ps.o, scale(ps.d, hit.t));      // the point shadeFakeMaterial will shade (:392)
+            float *rf = reinterpret_cast<float *>(rec);
+            rf[0 * TILE + slot] = sp.x; rf[1 * TILE + slot] = sp.y; rf[2 * TILE + slot] = sp.z;
+            rf[3 * TILE + slot] = ps.d.x; rf[4 * TILE + slot] = ps.d.y; rf[5 * TILE + slot] = ps.d.z;
+            rf[6 * TILE + slot] = ps.color.x; rf[7 * TILE + slot] = ps.color.y; rf[8 * TILE + slot] = ps.color.z;
+            rf[9 * TILE + slot] = hit.n.x; rf[10 * TILE + slot] = hit.n.y; rf[11 * TILE + slot] = hit.n.z;
+            rf[12 * TILE + slot] = hit.u; rf[13 * TILE + slot] = hit.v;
+            rec[14 * TILE + slot] = pix;
+            rec[15 * TILE + slot] = hit.mat | (hit.geom << 16);
+            rec[16 * TILE + slot] = stage_key(bin, r_all, r_scat);
+        }
+        __syncthreads();
+        {
+            const int npend = toff[nb];
+            const size_t gi = (size_t)tile * TILE + tid;
+            if (tid < npend) {
+                const float *rf = reinterpret_cast<const float *>(rec);
+                stage.px[gi] = rf[0 * TILE + tid]; stage.py[gi] = rf[1 * TILE + tid]; stage.pz[gi] = rf[2 * TILE + tid];
+                stage.dx[gi] = rf[3 * TILE + tid]; stage.dy[gi] = rf[4 * TILE + tid]; stage.dz[gi] = rf[5 * TILE + tid];
+                stage.cr[gi] = rf[6 * TILE + tid]; stage.cg[gi] = rf[7 * TILE + tid]; stage.cb[gi] = rf[8 * TILE + tid];
+                stage.nx[gi] = rf[9 * TILE + tid]; stage.ny[gi] = rf[10 * TILE + tid]; stage.nz[gi] = rf[11 * TILE + tid];
+                if (p.uses_uv) { stage.u[gi] = rf[12 * TILE + tid]; stage.v[gi] = rf[13 * TILE + tid]; }
+                stage.pix[gi] = rec[14 * TILE + tid];
+                stage.mg[gi] = rec[15 * TILE + tid];
+                stage.idx[gi] = rec[16 * TILE + tid];
+            } else {
+                stage.idx[gi] = -1;
             }
         }
         __syncthreads();
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(TILE) void k_bounce(const BounceParams p) {
 
 struct MoveParams {
     PathSoA stage, out;
-    int32_t nbins, maxTiles, first, owned, nsuper;
+    int32_t nbins, maxTiles, first, owned, nsuper, uses_uv;
     const int32_t *totals_prev;
     const int32_t *counts_all, *counts_scat, *chunk_all, *chunk_scat, *super_all, *super_scat, *totals_all, *totals_scat;
     size_t seg_stage, seg_out, seg_counts, seg_chunk, seg_totals;      // per-segment strides, as in BounceParams
@@ -317,23 +351,48 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
         if (lane == 0) (which ? base_scat : base_all)[b] = s;
     }
     __syncthreads();
-    for (int tile = tile0; tile < tile1; tile++) {
-        const int i = tile * TILE + tid;
-        if (i >= n_in) continue;
-        const int bin = stage.idx[i];
-        if (bin < 0) continue;
-        const int r = stage.rank[i];
-        const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + (r & 0xffff);
-        const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + (r >> 16);
-        out.ox[pos] = stage.ox[i]; out.oy[pos] = stage.oy[i]; out.oz[pos] = stage.oz[i];
-        out.dx[pos] = stage.dx[i]; out.dy[pos] = stage.dy[i]; out.dz[pos] = stage.dz[i];
-        out.cr[pos] = stage.cr[i]; out.cg[pos] = stage.cg[i]; out.cb[pos] = stage.cb[i];
-        out.t[pos] = stage.t[i];
-        out.nx[pos] = stage.nx[i]; out.ny[pos] = stage.ny[i]; out.nz[pos] = stage.nz[i];
-        out.u[pos] = stage.u[i]; out.v[pos] = stage.v[i];
-        out.pix[pos] = stage.pix[i];
-        out.mg[pos] = stage.mg[i];
-        out.idx[pos] = idx;
+    // MOVE_U tiles per step: all loads of a step are issued before the first store, which is what hides the HBM
+    // latency here (one tile's 15 loads per lane in flight is not enough at 8 waves per SIMD)
+    constexpr int MOVE_U = 4;
+    for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
+        size_t i[MOVE_U];
+        int32_t key[MOVE_U];
+#pragma unroll
+        for (int u = 0; u < MOVE_U; u++) {
+            const int tile = tbase + u;
+            i[u] = (size_t)min(tile, tile1 - 1) * TILE + tid;
+            key[u] = stage.idx[i[u]];
+            if (tile >= tile1) key[u] = -1;
+        }
+        float f[MOVE_U][14];
+        int32_t pixv[MOVE_U], mgv[MOVE_U];
+#pragma unroll
+        for (int u = 0; u < MOVE_U; u++) {
+            if (key[u] != -1) {
+                f[u][0] = stage.px[i[u]]; f[u][1] = stage.py[i[u]]; f[u][2] = stage.pz[i[u]];
+                f[u][3] = stage.dx[i[u]]; f[u][4] = stage.dy[i[u]]; f[u][5] = stage.dz[i[u]];
+                f[u][6] = stage.cr[i[u]]; f[u][7] = stage.cg[i[u]]; f[u][8] = stage.cb[i[u]];
+                f[u][9] = stage.nx[i[u]]; f[u][10] = stage.ny[i[u]]; f[u][11] = stage.nz[i[u]];
+                if (p.uses_uv) { f[u][12] = stage.u[i[u]]; f[u][13] = stage.v[i[u]]; }
+                pixv[u] = stage.pix[i[u]]; mgv[u] = stage.mg[i[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MOVE_U; u++) {
+            if (key[u] == -1) continue;
+            const int tile = tbase + u;
+            const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
+            const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + r_all;
+            const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + r_scat;
+            out.px[pos] = f[u][0]; out.py[pos] = f[u][1]; out.pz[pos] = f[u][2];
+            out.dx[pos] = f[u][3]; out.dy[pos] = f[u][4]; out.dz[pos] = f[u][5];
+            out.cr[pos] = f[u][6]; out.cg[pos] = f[u][7]; out.cb[pos] = f[u][8];
+            out.nx[pos] = f[u][9]; out.ny[pos] = f[u][10]; out.nz[pos] = f[u][11];
+            if (p.uses_uv) { out.u[pos] = f[u][12]; out.v[pos] = f[u][13]; }
+            out.pix[pos] = pixv[u];
+            out.mg[pos] = mgv[u];
+            out.idx[pos] = idx;
+        }
     }
 }
 
@@ -520,6 +579,7 @@ struct ptx_tracer {
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
     int kmax = 1;                                        // iterations per launch set (segments)
+    int uses_uv = 0;
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
@@ -550,9 +610,9 @@ namespace {
 
 // field arrays of `stride` elements each (stride = segments x cap: segment s of a field starts at s*cap)
 void carve(PathSoA &s, float *f, int32_t *i, size_t stride) {
-    float **fp[SOA_FLOATS] = {&s.ox, &s.oy, &s.oz, &s.dx, &s.dy, &s.dz, &s.cr, &s.cg, &s.cb, &s.t, &s.nx, &s.ny, &s.nz, &s.u, &s.v};
+    float **fp[SOA_FLOATS] = {&s.px, &s.py, &s.pz, &s.dx, &s.dy, &s.dz, &s.cr, &s.cg, &s.cb, &s.nx, &s.ny, &s.nz, &s.u, &s.v};
     for (int k = 0; k < SOA_FLOATS; k++) *fp[k] = f + (size_t)k * stride;
-    s.pix = i; s.mg = i + stride; s.idx = i + 2 * stride; s.rank = i + 3 * stride;
+    s.pix = i; s.mg = i + stride; s.idx = i + 2 * stride;
 }
 
 void camera_to_device(const ptx_camera &c, DCamera &d) {
@@ -584,7 +644,7 @@ int free_tracer(ptx_tracer *t) {
 int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
     const int triWords = t->tri_lds ? ((t->ntri * 9 + 3) & ~3) : 0;
-    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb);
+    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb + 2 * nb + 1 + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
@@ -642,7 +702,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
         bp.stage = t->soa[1];
         bp.image = t->d_image;
         bp.iter = iter_first; bp.traceDepth = t->traceDepth; bp.bounce = b;
-        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.totals_prev = first ? nullptr : totals(b - 1, 1);
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
@@ -663,7 +723,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
             mp.stage = t->soa[1];
             const bool to_cache = (first && cache_on);
             mp.out = to_cache ? t->soa[2] : t->soa[0];
-            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper;
+            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper; mp.uses_uv = t->uses_uv;
             mp.totals_prev = bp.totals_prev;
             mp.counts_all = counts_all; mp.counts_scat = counts_scat;
             mp.chunk_all = chunk_all; mp.chunk_scat = chunk_scat;
@@ -686,7 +746,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, t->stream));
             const size_t fstride = (first && cache_on) ? (size_t)t->cap : t->field_stride;
             for (int f = 0; f < SOA_FLOATS; f++)
-                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.ox + (size_t)f * fstride,
+                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.px + (size_t)f * fstride,
                                         sizeof(float) * (size_t)t->cap, hipMemcpyDeviceToDevice, t->stream));
             t->cap_filled = true;
         }
@@ -761,8 +821,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     if (opt.tile_world <= 1) owned_rows = H;
     else for (int y = 0; y < H; y++) if ((y / opt.tile_rows) % opt.tile_world == opt.tile_rank) owned_rows++;
     t->tm.owned = owned_rows * W;
-    t->cap = t->tm.owned > 0 ? t->tm.owned : 1;
-    t->maxTiles = (t->cap + TILE - 1) / TILE;
+    t->maxTiles = (std::max(t->tm.owned, 1) + TILE - 1) / TILE;
+    t->cap = t->maxTiles * TILE;                          // whole tiles: the stage is written tile by tile
     t->nbins = opt.sort_by_material ? (nmaterials > 0 ? nmaterials : 1) : 1;
     t->maxBounces = trace_depth;
     hipDeviceProp_t prop;
@@ -793,6 +853,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             if (tx[k]->channels > 0 && tx[k]->image && tx[k]->width > 0 && tx[k]->height > 0) {
                 if (tx[k]->channels < 3) { set_error(PTX_ERR_UNSUPPORTED, "textures need >= 3 channels"); return fail(PTX_ERR_UNSUPPORTED); }
                 dt.w = tx[k]->width; dt.h = tx[k]->height; dt.ch = tx[k]->channels; dt.off = htex.size();
+                t->uses_uv = 1;
                 size_t nbytes = (size_t)dt.w * dt.h * dt.ch;
                 htex.insert(htex.end(), tx[k]->image, tx[k]->image + nbytes);
             }
@@ -1115,7 +1176,7 @@ int ptx_debug_set_capture(ptx_tracer *t, int bounce) {
 }
 
 int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx, int32_t *material,
-                          float *fields15, int cap) {
+                          float *fields14, int cap) {
     if (!t || !n_out) return set_error(PTX_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
@@ -1133,9 +1194,9 @@ int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32
         std::vector<int32_t> mg((size_t)m);
         HIPCHECK(hipMemcpy(mg.data(), t->d_cap + 2 * (size_t)t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
         for (int k = 0; k < m; k++) material[k] = mg[k] & 0xffff;
-        if (fields15)       // 15 rows of m floats: ox oy oz dx dy dz cr cg cb t nx ny nz u v
+        if (fields14)       // 14 rows of m floats: px py pz dx dy dz cr cg cb nx ny nz u v
             for (int f = 0; f < SOA_FLOATS; f++)
-                HIPCHECK(hipMemcpy(fields15 + (size_t)f * m, t->d_cap_f + (size_t)f * t->cap, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(fields14 + (size_t)f * m, t->d_cap_f + (size_t)f * t->cap, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
     }
     return PTX_OK;
 }

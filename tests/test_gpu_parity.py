@@ -164,13 +164,14 @@ def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
         assert beq(g["idx"], want_idx)
         assert beq(g["pix"], paths["pixelIndex"][pend])
         assert beq(g["mat"], isects["materialId"][pend])
-        for k, nm in enumerate(("ox", "oy", "oz")):
-            assert beq(g[nm], paths["origin"][pend][:, k])
+        # the stream carries the point that will be shaded, origin + t * direction (src/pathtrace.cu:392), in fp32
+        sp = paths["origin"][pend] + isects["t"][pend][:, None] * paths["direction"][pend]
+        for k, nm in enumerate(("px", "py", "pz")):
+            assert beq(g[nm], sp[:, k])
         for k, nm in enumerate(("dx", "dy", "dz")):
             assert beq(g[nm], paths["direction"][pend][:, k])
         for k, nm in enumerate(("cr", "cg", "cb")):
             assert beq(g[nm], paths["color"][pend][:, k])
-        assert beq(g["t"], isects["t"][pend])
         for k, nm in enumerate(("nx", "ny", "nz")):
             assert beq(g[nm], isects["normal"][pend][:, k])
     T.close()
