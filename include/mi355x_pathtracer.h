@@ -90,7 +90,8 @@ typedef struct ptx_options {
     int32_t device;              /* HIP device ordinal, -1 = current device */
     int32_t batch;               /* iterations traced per launch set by ptx_render (independent streams, results
                                     identical to one at a time); 0 = choose from the tile size */
-    int32_t reserved[6];
+    int32_t no_lds_triangles;    /* 1 = read the triangle table from global memory even when it would fit in LDS */
+    int32_t reserved[5];
 } ptx_options;
 
 typedef struct ptx_stats {

@@ -373,12 +373,14 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
     return tmin;
 }
 // geometric normal (+ optional tangent-space bump map) of the chosen face, src/intersections.h:237-279
-PT_DEV vec3 meshNormal(const DScene &sc, const DGeom &geom, const Cand &c) {
+// geoN = the unperturbed normal (the reference derives its unused `outside` flag from it, :243)
+PT_DEV vec3 meshNormal(const DScene &sc, const DGeom &geom, const Cand &c, vec3 &geoN) {
     const float *__restrict__ tri = sc.faces + ((size_t)geom.faceStart + c.face) * 15;
     vec3 e1 = sub(ld3(tri + 5), ld3(tri));
     vec3 e2 = sub(ld3(tri + 10), ld3(tri));
     vec3 objN = normalize(cross(e1, e2));
     vec3 normal = normalize(multiplyMV(geom.invT, objN, 0.f));
+    geoN = normal;
     const DTex &bump = geom.tex[3];
     if (geom.type == G_OBJ && bump.ch) {
         float dUV1x = tri[8] - tri[3], dUV1y = tri[9] - tri[4];
@@ -450,7 +452,7 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
         h.u = best.u; h.v = best.v;
         if (geom.type == G_CUBE) h.n = boxNormal(geom, best);
         else if (geom.type == G_SPHERE) h.n = sphereNormal(geom, best);
-        else h.n = meshNormal(sc, geom, best);
+        else { vec3 geoN; h.n = meshNormal(sc, geom, best, geoN); }
     }
 }
 
@@ -477,8 +479,9 @@ PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &g, Ray r, vec3 
         q.o = multiplyMV(g.inv, r.o, 1.0f);
         q.d = normalize(multiplyMV(g.inv, r.d, 0.0f));
         point = multiplyMV(g.xf, getPointOnRay(q, t), 1.f);
-        normal = meshNormal(sc, g, c);
-        outside = dot(normal, r.d) < 0;
+        vec3 geoN;
+        normal = meshNormal(sc, g, c, geoN);
+        outside = dot(geoN, r.d) < 0;
     }
     return t;
 }

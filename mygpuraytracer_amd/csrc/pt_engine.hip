@@ -778,7 +778,7 @@ int ptx_device_count(void) {
 void ptx_default_options(ptx_options *o) {
     memset(o, 0, sizeof *o);
     o->depth_of_field = 0; o->cache_first_bounce = 1; o->sort_by_material = 1; o->antialiasing = 1; o->bounding_box = 0;
-    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0;
+    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0;
 }
 
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
@@ -867,7 +867,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         float *o = &htri9[(size_t)j * 9];
         for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
     }
-    t->tri_lds = (t->ntri > 0 && (size_t)t->ntri * 36 <= 32768) ? 1 : 0;     // <= 32 KB keeps 4 workgroups per CU
+    // the table goes to LDS when it leaves room for at least 2 workgroups per CU (160 KB LDS, ~19 KB of sort buffers)
+    t->tri_lds = (t->ntri > 0 && (size_t)t->ntri * 36 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
     if (hfaces.empty()) hfaces.resize(15, 0.f);
     if (htex.empty()) htex.resize(16, 0);
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));

@@ -172,6 +172,15 @@ void ref_get_faces(void *h, int g, float *out) {
     }
 }
 
+// texture of a geom as pathtraceInit would upload it: which = 0 kd, 1 ks, 2 ke, 3 bump; whc = width, height, channels;
+// pixels may be NULL to query the size only
+void ref_get_texture(void *h, int g, int which, int *whc, unsigned char *pixels) {
+    const Geom &ge = ((RefState *)h)->geoms[g];
+    const Texture *t = which == 0 ? &ge.kd : which == 1 ? &ge.ks : which == 2 ? &ge.ke : &ge.bump;
+    whc[0] = t->width; whc[1] = t->height; whc[2] = t->channels;
+    if (pixels && t->image && t->channels) memcpy(pixels, t->image, (size_t)t->width * t->height * t->channels);
+}
+
 // camera dump: resolution(2 ints) ; position lookAt view up right (15 floats) fov(2) pixelLength(2) ;
 // iterations, traceDepth
 void ref_get_camera(void *h, int *ints4, float *f19) {

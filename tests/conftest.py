@@ -39,8 +39,26 @@ def dump_from_golden(g, cam="cam_floats_runcuda", res=None):
     faces = [g["faces_%d" % i] for i in range(ng)]
     ci = g["cam_ints"].copy()
     cf = g[cam].copy()
+    textures = {}
+    for k in g.files:
+        if k.startswith("tex_"):
+            _, gi, which = k.split("_")
+            textures[(int(gi), int(which))] = g[k]
     return dict(geom_ints=g["geom_ints"], geom_trs=g["geom_trs"], geom_mats=g["geom_mats"], materials=g["materials"],
-                faces=faces, cam_ints=ci, cam_floats=cf)
+                faces=faces, cam_ints=ci, cam_floats=cf, textures=textures)
+
+
+def ensure_standin_assets():
+    """The stand-in mesh's procedural textures are generated (deterministically) rather than committed."""
+    if not os.path.exists(os.path.join(ROOT, "textures", "standin_kd.ppm")):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_standin_mesh
+        make_standin_mesh.main(128)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def standin_assets():
+    ensure_standin_assets()
 
 
 @pytest.fixture(scope="session")

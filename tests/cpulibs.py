@@ -189,6 +189,7 @@ class RefLib(_Tracer):
         L.ref_get_material.argtypes = [vp, C.c_int, vp]
         L.ref_get_faces.argtypes = [vp, C.c_int, vp]
         L.ref_get_camera.argtypes = [vp, vp, vp]
+        L.ref_get_texture.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.ref_set_depth.argtypes = [vp, C.c_int]
         L.ref_apply_runcuda_camera.argtypes = [vp]
         L.ref_set_options.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -239,8 +240,17 @@ class RefLib(_Tracer):
         L.ref_get_camera(h, _ptr(ci), _ptr(cf))
         tv = np.zeros(4, np.int32)
         L.ref_texture_vector_sizes(h, _ptr(tv))
+        textures = {}
+        for i in range(ng):
+            for which in range(4):
+                whc = np.zeros(3, np.int32)
+                L.ref_get_texture(h, i, which, _ptr(whc), None)
+                if whc[2] > 0:
+                    img = np.zeros((int(whc[1]), int(whc[0]), int(whc[2])), np.uint8)
+                    L.ref_get_texture(h, i, which, _ptr(whc), _ptr(img))
+                    textures[(i, which)] = img
         return dict(geom_ints=gints, geom_trs=gfl[:, :9].copy(), geom_mats=gfl[:, 9:].copy(), materials=mats,
-                    faces=faces, cam_ints=ci, cam_floats=cf, texture_vector_sizes=tv)
+                    faces=faces, cam_ints=ci, cam_floats=cf, texture_vector_sizes=tv, textures=textures)
 
 
 class OracleLib(_Tracer):
@@ -289,6 +299,8 @@ class OracleLib(_Tracer):
             if len(f):
                 f = np.ascontiguousarray(f, np.float32)
                 self.lib.o_scene_set_faces(self.h, gi, len(f), _ptr(f))
+        if textures is None:
+            textures = dump.get("textures")
         for (gi, which), img in (textures or {}).items():
             img = np.ascontiguousarray(img, np.uint8)
             hh, ww, ch = img.shape

@@ -86,6 +86,19 @@ SCALE       2 4 2
 """
 
 
+REPO_ROOT = os.path.dirname(os.path.dirname(HERE))
+REPO_SCENES = os.path.join(REPO_ROOT, "scenes")
+
+
+def ship_text(res=None, depth=None):
+    """The stand-in for the reference's (missing) spaceship scene lives in this repo; it is loaded BY THE REFERENCE
+    LOADER all the same (textures through stb_image)."""
+    sys.path.insert(0, os.path.join(REPO_ROOT, "tools"))
+    import make_standin_mesh
+    make_standin_mesh.main(128)
+    return scene_text_with(open(os.path.join(REPO_SCENES, "cornellSpaceship.txt")).read(), res, depth)
+
+
 def ref_text(name, res=None, depth=None):
     return scene_text_with(open(os.path.join(REFERENCE_ROOT, "scenes", name)).read(), res, depth)
 
@@ -136,6 +149,20 @@ def main():
             out["faces_%d" % gi] = f
         np.savez_compressed(os.path.join(HERE, "loader_%s.npz" % name[:-4]), **out)
 
+    R.load_text(ship_text(), cwd=REPO_SCENES)
+    d = R.dump()
+    R.apply_runcuda_camera()
+    out = dict(geom_ints=d["geom_ints"], geom_trs=d["geom_trs"], geom_mats=d["geom_mats"], materials=d["materials"],
+               cam_ints=d["cam_ints"], cam_floats=d["cam_floats"], cam_floats_runcuda=R.dump()["cam_floats"],
+               cam_floats_1080p=d["cam_floats"], texture_vector_sizes=d["texture_vector_sizes"])
+    for gi, f in enumerate(d["faces"]):
+        out["faces_%d" % gi] = f
+    for (gi, which), img in d["textures"].items():
+        out["tex_%d_%d" % (gi, which)] = img
+    np.savez_compressed(os.path.join(HERE, "loader_cornellSpaceship.npz"), **out)
+    rays = random_rays(rng, 2048, d["geom_trs"][8][:3].astype(np.float64), 1.6)
+    np.savez_compressed(os.path.join(HERE, "isect_kat_cornellSpaceship.npz"), rays_8=rays, out_8=R.geom_test(8, rays))
+
     # ---- per-geom intersection KATs -----------------------------------------------------------------------------
     for name in ("cornellGlass.txt", "cornellObj.txt"):
         R.load(os.path.join(REFERENCE_ROOT, "scenes", name))
@@ -152,8 +179,9 @@ def main():
     # ---- shade / scatterRay KATs: real (path, intersection) pairs captured mid-render -----------------------------
     cases = [("glass", ref_text("cornellGlass.txt", (48, 48), 8)), ("obj", ref_text("cornellObj.txt", (48, 48), 8)),
              ("mirror0", MIRROR_SCENE % "0"), ("mirror20", MIRROR_SCENE % "20.5")]
+    cases.append(("ship", ship_text((48, 48), 8)))
     for tag, text in cases:
-        R.load_text(text)
+        R.load_text(text, cwd=REPO_SCENES if tag == "ship" else os.path.join(REFERENCE_ROOT, "scenes"))
         R.apply_runcuda_camera()
         R.pt_init()
         out = {}
@@ -183,8 +211,9 @@ def main():
         ("nosort_obj", ref_text("cornellObj.txt", (96, 54), 8), dict(aa=1, dof=0, sort=0, cache=0)),
         ("mirror20", MIRROR_SCENE % "20.5", dict(aa=1, dof=0, sort=1, cache=1)),
     ]
+    configs.append(("c5_ship", ship_text((96, 54), 8), dict(aa=1, dof=1, sort=1, cache=1)))
     for tag, text, opt in configs:
-        R.load_text(text)
+        R.load_text(text, cwd=REPO_SCENES if tag == "c5_ship" else os.path.join(REFERENCE_ROOT, "scenes"))
         R.apply_runcuda_camera()
         R.set_options(**opt)
         R.pt_init()

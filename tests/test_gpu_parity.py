@@ -53,12 +53,14 @@ def test_device_libm_bit_identical(gpu_product, O):
     T.close()
 
 
-@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj"])
+@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj", "cornellSpaceship"])
 def test_intersection_kats_on_device(gpu_product, O, scene):
     """The golden per-geom vectors (produced by the reference's own box/sphere/mesh tests) through the device functions."""
     k = golden("isect_kat_%s.npz" % scene)
     s, T = make_pair(gpu_product, O, scene + ".txt", (16, 16), 8)
     for gi in range(s.num_geoms):
+        if "rays_%d" % gi not in k.files:
+            continue
         out = T.geom_test(gi, k["rays_%d" % gi])
         ref = k["out_%d" % gi]
         hit = ref[:, 0] > 0
@@ -71,6 +73,7 @@ def test_intersection_kats_on_device(gpu_product, O, scene):
     ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),
     ("cornellGlass.txt", (96, 54), 12, dict(depth_of_field=1)),
     ("cornellObj.txt", (96, 54), 8, {}),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(depth_of_field=1)),
 ])
 def test_stage_parity(gpu_product, O, scene, res, depth, opt):
     """generateRayFromCamera, computeIntersections and shadeFakeMaterial one at a time on identical inputs."""
@@ -97,7 +100,7 @@ def test_stage_parity(gpu_product, O, scene, res, depth, opt):
     T.close()
 
 
-@pytest.mark.parametrize("tag", ["glass", "obj", "mirror0", "mirror20"])
+@pytest.mark.parametrize("tag", ["glass", "obj", "mirror0", "mirror20", "ship"])
 def test_shade_golden_on_device(gpu_product, O, tag):
     """Golden (path, intersection) -> shaded path vectors captured from reference renders.  The expected values were
     produced with glibc's libm, the device runs the portable one: identical wherever no sin/cos/pow is involved
@@ -112,7 +115,7 @@ def test_shade_golden_on_device(gpu_product, O, tag):
         s = gpu_product.Scene(f.name, base_dir=os.path.join(ROOT, "scenes"))
         os.unlink(f.name)
     else:
-        s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt" if tag == "glass" else "cornellObj.txt"))
+        s = gpu_product.Scene(os.path.join(ROOT, "scenes", dict(glass="cornellGlass.txt", obj="cornellObj.txt", ship="cornellSpaceship.txt")[tag]))
     T = gpu_product.Tracer(s)
     _scene_for_shade(O, tag)
     O.set_libm(1)
@@ -144,6 +147,8 @@ def oracle_pending_stream(O, it, bounce):
     ("cornellObj.txt", (96, 54), 8, {}),
     ("cornellObj.txt", (96, 54), 8, dict(sort_by_material=0)),
     ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(depth_of_field=1)),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(no_lds_triangles=1)),
 ])
 def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
     """The permutation is the observable: after each bounce the device stream holds exactly the reference's sorted
@@ -174,12 +179,16 @@ def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
             assert beq(g[nm], paths["color"][pend][:, k])
         for k, nm in enumerate(("nx", "ny", "nz")):
             assert beq(g[nm], isects["normal"][pend][:, k])
+        if s.dump()["textures"]:                                   # texcoords travel only when some texture exists
+            obj = s.dump()["geom_ints"][isects["geomId"][pend], 0] == 3
+            assert beq(g["u"][obj], isects["texcoord"][pend][obj, 0]) and beq(g["v"][obj], isects["texcoord"][pend][obj, 1])
     T.close()
 
 
 RENDER_CASES = [
     ("c1_sphere", "sphere.txt", (64, 64), 4), ("c2_cornell_cache", "cornell.txt", (64, 64), 8), ("c3_glass", "cornellGlass.txt", (96, 54), 12),
     ("c4_obj", "cornellObj.txt", (96, 54), 8), ("c5_dof", "cornellGlass.txt", (96, 54), 8), ("nosort_obj", "cornellObj.txt", (96, 54), 8),
+    ("c5_ship", "cornellSpaceship.txt", (96, 54), 8),
 ]
 
 

@@ -41,6 +41,21 @@ def test_loader_matches_reference_dump(product, scene):
     assert beq(s2.dump()["cam_floats"], g["cam_floats_1080p"])
 
 
+def test_textured_standin_scene_matches_reference_loader(product):
+    """config 5 stand-in: OBJ with uv, Ni 2.0 and four PPM maps -- geoms, triangles (quad split), material and the
+    texels (stb_image's vertical flip) equal what the reference loader produced from the same files."""
+    g = golden("loader_cornellSpaceship.npz")
+    d = product.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship.txt")).dump()
+    for k in ("geom_ints", "geom_trs", "geom_mats", "materials", "cam_floats"):
+        assert beq(d[k], g[k]), k
+    assert d["geom_ints"][8].tolist() == [3, 6, 288] and list(g["texture_vector_sizes"]) == [9, 9, 9, 9]
+    for gi, f in enumerate(d["faces"]):
+        assert beq(f, g["faces_%d" % gi])
+    assert sorted(d["textures"]) == [(8, 0), (8, 1), (8, 2), (8, 3)]
+    for (gi, which), img in d["textures"].items():
+        assert np.array_equal(img, g["tex_%d_%d" % (gi, which)])
+
+
 def test_obj_has_own_material_and_empty_textures(product):
     """cornellObj: the OBJ geom gets a material appended from the first .mtl entry (scene.cpp:221-231) and four
     empty texture slots (the reference's scene-wide texture vectors are one short here: fixture says 6 < 7)."""

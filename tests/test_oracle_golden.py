@@ -46,13 +46,15 @@ def test_loader_arithmetic(O, scene):
     assert np.allclose(O.cam_floats[:3], [0, 4.99999952, 10.5], atol=1e-6)
 
 
-@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj"])
+@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj", "cornellSpaceship"])
 def test_intersection_kats(O, scene):
     """boxIntersectionTest / sphereIntersectionTest / meshIntersectionTest on 1024 rays per geom."""
     g = golden("loader_%s.npz" % scene)
     k = golden("isect_kat_%s.npz" % scene)
     O.create(dump_from_golden(g))
     for gi in range(len(g["geom_ints"])):
+        if "rays_%d" % gi not in k.files:
+            continue                          # the spaceship fixture covers its bump-mapped mesh only
         out = O.geom_test(gi, k["rays_%d" % gi])
         ref = k["out_%d" % gi]
         hit = ref[:, 0] > 0
@@ -68,16 +70,18 @@ def _scene_for_shade(O, tag):
         O.create(dump_from_golden(golden("loader_cornellGlass.npz")))
     elif tag == "obj":
         O.create(dump_from_golden(golden("loader_cornellObj.npz")))
+    elif tag == "ship":
+        O.create(dump_from_golden(golden("loader_cornellSpaceship.npz")))
     else:
         O.create(product_dump_from_text(bytes(k["scene_text"]).decode()))
     return k
 
 
-@pytest.mark.parametrize("tag", ["glass", "obj", "mirror0", "mirror20"])
+@pytest.mark.parametrize("tag", ["glass", "obj", "mirror0", "mirror20", "ship"])
 def test_shade_kats(O, tag):
     """shadeFakeMaterial + scatterRay on (path, intersection) pairs captured from reference renders: diffuse,
     refractive (enter / exit / total internal reflection), mirror with exponent 0 and 20.5, OBJ spec/diffuse,
-    light, miss."""
+    textured OBJ (Kd / Ks / emissive Ke texels, bump-mapped normals), light, miss."""
     k = _scene_for_shade(O, tag)
     keys = sorted(x[:-6] for x in k.files if x.endswith("_paths"))
     assert keys
@@ -89,9 +93,10 @@ def test_shade_kats(O, tag):
     assert total > 2000
 
 
-RENDERS = ["c1_sphere", "c2_cornell_cache", "c3_glass", "c4_obj", "c5_dof", "nosort_obj", "mirror20"]
+RENDERS = ["c1_sphere", "c2_cornell_cache", "c3_glass", "c4_obj", "c5_dof", "nosort_obj", "mirror20", "c5_ship"]
 RENDER_SCENE = dict(c1_sphere=("sphere", (64, 64), 4), c2_cornell_cache=("cornell", (64, 64), 8), c3_glass=("cornellGlass", (96, 54), 12),
-                    c4_obj=("cornellObj", (96, 54), 8), c5_dof=("cornellGlass", (96, 54), 8), nosort_obj=("cornellObj", (96, 54), 8))
+                    c4_obj=("cornellObj", (96, 54), 8), c5_dof=("cornellGlass", (96, 54), 8), nosort_obj=("cornellObj", (96, 54), 8),
+                    c5_ship=("cornellSpaceship", (96, 54), 8))
 
 
 def oracle_for_render(O, tag):
