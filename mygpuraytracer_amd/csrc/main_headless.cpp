@@ -1,0 +1,92 @@
+// main_headless.cpp -- the reference's main.cpp/preview.cpp without the window (src/main.cpp:36-152):
+// load the scene, recompute the camera as the first runCuda() does, pathtraceFree/pathtraceInit, run
+// state.iterations iterations of pathtrace, print "time: <ms>" (sum of the bounce-loop timer, main.cpp:141-146) and
+// save <FILE>.<utc>.<n>samp.png with saveImage's mirroring (main.cpp:81-102).
+//
+//   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm]
+//                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
+//
+// RES / DEPTH / ITERATIONS overrides and the four switches are what the reference can only change by editing the
+// scene file or the #defines of src/pathtrace.cu:36-40.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pathtrace_api.h"
+#include "pt_image.h"
+
+static std::string currentTimeString() {          // src/preview.cpp:13-19
+    time_t now;
+    time(&now);
+    char buf[sizeof "0000-00-00_00-00-00z"];
+    strftime(buf, sizeof buf, "%Y-%m-%d_%H-%M-%Sz", gmtime(&now));
+    return std::string(buf);
+}
+
+int main(int argc, char **argv) {
+    const std::string startTimeString = currentTimeString();
+    if (argc < 2) {
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]\n", argv[0]);
+        return 1;
+    }
+    int resw = 0, resh = 0, depth = 0, iterations = 0;
+    bool pfm = false;
+    std::string out_prefix;
+    ptx_options &opt = pathtraceOptions();
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "%s needs %d value(s)\n", a.c_str(), n); exit(1); } };
+        if (a == "--res") { need(2); resw = atoi(argv[++i]); resh = atoi(argv[++i]); }
+        else if (a == "--depth") { need(1); depth = atoi(argv[++i]); }
+        else if (a == "--iterations") { need(1); iterations = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); out_prefix = argv[++i]; }
+        else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
+        else if (a == "--pfm") pfm = true;
+        else if (a == "--no-aa") opt.antialiasing = 0;
+        else if (a == "--dof") opt.depth_of_field = 1;
+        else if (a == "--no-sort") opt.sort_by_material = 0;
+        else if (a == "--no-cache") opt.cache_first_bounce = 0;
+        else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+    }
+    Scene *scene = nullptr;
+    try {
+        scene = new Scene(argv[1]);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    if (resw > 0 && resh > 0) scene->setResolution(resw, resh);
+    if (depth > 0) scene->state.traceDepth = depth;
+    if (iterations > 0) scene->state.iterations = (unsigned)iterations;
+    scene->applyRunCudaCamera();
+    const int width = scene->state.camera.resolution[0], height = scene->state.camera.resolution[1];
+
+    pathtraceFree();
+    pathtraceInit(scene);
+    ptx_tracer *t = pathtraceHandle();
+    const int n = (int)scene->state.iterations;
+    if (ptx_render(t, 1, n) != PTX_OK || ptx_read_image(t, &scene->state.image[0].x) != PTX_OK) {
+        fprintf(stderr, "render failed: %s\n", ptx_last_error());
+        return 1;
+    }
+    ptx_stats st;
+    ptx_get_stats(t, &st);
+    printf("time: %g\n", st.loop_ms_total);                                             // main.cpp:146
+    printf("%d x %d, depth %d, %d samples: %.3f ms/iteration, %.1f Mrays/s\n", width, height, scene->state.traceDepth, n,
+           st.loop_ms_total / n, st.rays_total / (st.loop_ms_total * 1e-3) / 1e6);
+
+    std::ostringstream ss;                                                              // saveImage, main.cpp:94-97
+    ss << (out_prefix.empty() ? scene->state.imageName : out_prefix) << "." << startTimeString << "." << n << "samp";
+    std::vector<uint8_t> rgb8;
+    ptimg::to_rgb8_mirrored(width, height, &scene->state.image[0].x, (float)n, rgb8);
+    if (!ptimg::write_png_rgb8(ss.str() + ".png", width, height, rgb8.data())) { fprintf(stderr, "cannot write %s.png\n", ss.str().c_str()); return 1; }
+    printf("Saved %s.png.\n", ss.str().c_str());
+    if (pfm) { ptimg::write_pfm(ss.str() + ".pfm", width, height, &scene->state.image[0].x, (float)n); printf("Saved %s.pfm.\n", ss.str().c_str()); }
+    pathtraceFree();
+    delete scene;
+    return 0;
+}

@@ -1,0 +1,94 @@
+// pt_image.h -- image output with the semantics of the reference's saveImage + image::savePNG
+// (src/main.cpp:81-102, src/image.cpp:22-39), without stb_image_write: a self-contained PNG encoder (zlib stream
+// of stored blocks -- valid PNG, no compression) and a PFM writer for the raw fp32 frame.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace ptimg {
+
+inline uint32_t crc32(const uint8_t *d, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ d[i]) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+
+inline void put32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+
+inline void chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data) {
+    put32(png, (uint32_t)data.size());
+    std::vector<uint8_t> td(type, type + 4);
+    td.insert(td.end(), data.begin(), data.end());
+    png.insert(png.end(), td.begin(), td.end());
+    put32(png, crc32(td.data(), td.size()));
+}
+
+// rgb8: h rows of w*3 bytes, top row first
+inline bool write_png_rgb8(const std::string &path, int w, int h, const uint8_t *rgb8) {
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (w * 3 + 1));
+    for (int y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), rgb8 + (size_t)y * w * 3, rgb8 + (size_t)(y + 1) * w * 3); }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    put32(z, (b << 16) | a);
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(png, "IHDR", ihdr);
+    chunk(png, "IDAT", z);
+    chunk(png, "IEND", {});
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
+    fclose(f);
+    return ok;
+}
+
+// saveImage (src/main.cpp:81-92) + savePNG (src/image.cpp:22-33): pixel (x, y) of the accumulation buffer, divided by
+// the sample count, goes to column W-1-x; clamp to [0,1], times 255, truncate.
+inline void to_rgb8_mirrored(int w, int h, const float *sum_rgb, float samples, std::vector<uint8_t> &out) {
+    out.resize((size_t)w * h * 3);
+    for (int x = 0; x < w; x++)
+        for (int y = 0; y < h; y++) {
+            const float *p = sum_rgb + ((size_t)x + (size_t)y * w) * 3;
+            uint8_t *o = &out[((size_t)(w - 1 - x) + (size_t)y * w) * 3];
+            for (int k = 0; k < 3; k++) {
+                float v = p[k] / samples;
+                v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                o[k] = (uint8_t)(v * 255.f);
+            }
+        }
+}
+
+// raw fp32 frame (PFM, bottom row first as the format demands), mean radiance = sum / samples, not mirrored
+inline bool write_pfm(const std::string &path, int w, int h, const float *sum_rgb, float samples) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+    std::vector<float> row((size_t)w * 3);
+    for (int y = h - 1; y >= 0; y--) {
+        for (int i = 0; i < w * 3; i++) row[i] = sum_rgb[(size_t)y * w * 3 + i] / samples;
+        fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    fclose(f);
+    return true;
+}
+
+}  // namespace ptimg

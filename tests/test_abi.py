@@ -61,3 +61,35 @@ def test_cpu_stream_compaction_entry_points(product, oracle_lib):
     lib = product.load_library()
     assert [lib.sc_ilog2(v) for v in (1, 2, 3, 4, 1023, 1024)] == [0, 1, 1, 2, 9, 10]
     assert [lib.sc_ilog2ceil(v) for v in (1, 2, 3, 4, 1023, 1025)] == [0, 1, 2, 2, 10, 11]
+
+
+def test_png_writer_matches_saveimage_semantics(tmp_path):
+    """pt_image.h: saveImage's x-mirror + savePNG's clamp*255 truncation (src/main.cpp:86-92, src/image.cpp:26-31) and a
+    decodable PNG (checked with zlib / PIL-free parsing)."""
+    import struct
+    import subprocess
+    import zlib
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "%s/mygpuraytracer_amd/csrc/pt_image.h"\n'
+                   'int main(){ float img[2*2*3]={0.5f,1.f,3.f, 0.f,0.25f,-1.f, 2.f,2.f,2.f, 0.999f,0.5f,0.1f}; std::vector<uint8_t> o;'
+                   ' ptimg::to_rgb8_mirrored(2,2,img,2.f,o); return ptimg::write_png_rgb8("%s/o.png",2,2,o.data())?0:1; }\n' % (ROOT, tmp_path))
+    subprocess.check_call(["g++", "-std=c++17", "-o", str(tmp_path / "t"), str(src)])
+    subprocess.check_call([str(tmp_path / "t")])
+    data = (tmp_path / "o.png").read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (2, 2, 8, 2, 0, 0, 0)
+    raw = zlib.decompress(idat)
+    rows = [raw[1:7], raw[8:14]]
+    # row 0: pixel x=1 (0, .125, clamp(-.5)=0) then x=0 (.25, .5, clamp(1.5)=1)
+    assert list(rows[0]) == [0, 31, 0, 63, 127, 255]
+    assert list(rows[1]) == [127, 63, 12, 255, 255, 255]

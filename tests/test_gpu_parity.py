@@ -317,3 +317,28 @@ def test_batched_iterations_identical(gpu_product, batch, tile):
         assert A.stats()["rays_total"] == B.stats()["rays_total"]
         A.render(12, 3); B.render(12, 3)                               # a second call continues the accumulation
         assert np.array_equal(A.read_image().view(np.uint32), B.read_image().view(np.uint32))
+
+
+def test_headless_driver(gpu_product, tmp_path):
+    """mi355x_pathtrace = the reference's main.cpp without the window: same scene file, prints the timer sum, writes
+    <prefix>.<utc>.<n>samp.png mirrored in x like saveImage; its fp32 frame equals the library's."""
+    import glob
+    import subprocess
+    exe = os.path.join(ROOT, "mygpuraytracer_amd", "mi355x_pathtrace")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"), "headless"])
+    out = subprocess.check_output([exe, os.path.join(ROOT, "scenes", "cornellObj.txt"), "--res", "64", "48", "--depth", "5",
+                                   "--iterations", "3", "--out", str(tmp_path / "img"), "--pfm"], text=True)
+    assert "time: " in out and "Saved" in out
+    pfm = glob.glob(str(tmp_path / "img.*.3samp.pfm"))
+    png = glob.glob(str(tmp_path / "img.*.3samp.png"))
+    assert len(pfm) == 1 and len(png) == 1
+    raw = open(pfm[0], "rb").read()
+    header_end = raw.index(b"-1.0\n") + 5
+    frame = np.frombuffer(raw[header_end:], np.float32).reshape(48, 64, 3)[::-1]
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(64, 48), depth=5)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s) as T:
+        T.render(1, 3)
+        want = T.read_image().reshape(48, 64, 3) / np.float32(3)
+    assert np.array_equal(frame, want)
