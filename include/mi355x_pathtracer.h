@@ -91,7 +91,10 @@ typedef struct ptx_options {
     int32_t batch;               /* iterations traced per launch set by ptx_render (independent streams, results
                                     identical to one at a time); 0 = choose from the tile size */
     int32_t no_lds_triangles;    /* 1 = read the triangle table from global memory even when it would fit in LDS */
-    int32_t reserved[5];
+    int32_t apps_variant;        /* 1 = behave like the apps/src copy of the reference (the one its CMake builds):
+                                    finalGather adds color * PI (apps/src/pathtrace.cu:508) and iteration 1 fills an
+                                    albedo AOV (apps/src/pathtrace.cu:412-462, ptx_read_albedo) */
+    int32_t reserved[4];
 } ptx_options;
 
 typedef struct ptx_stats {
@@ -148,6 +151,9 @@ int ptx_render(ptx_tracer *t, int iter_first, int count);
 int ptx_synchronize(ptx_tracer *t);
 
 int ptx_read_image(ptx_tracer *t, float *host_rgb);     /* W*H*3 floats = sum over iterations (state.image) */
+int ptx_read_albedo(ptx_tracer *t, float *host_rgb);    /* RenderState.albedo of apps/src (apps_variant only)  */
+/* sendToGPU, apps/src/pathtrace.h:10: a finished (e.g. denoised) host frame -> 8-bit preview, no division by iter */
+int ptx_write_denoised_pbo(ptx_tracer *t, const float *host_rgb, uint8_t *host_rgba);
 float *ptx_device_image(ptx_tracer *t);                 /* device pointer of the accumulation buffer        */
 int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba);          /* sendImageToPBO, pathtrace.cu:69 */
 int ptx_write_pbo_device(ptx_tracer *t, int iter, void *device_uchar4);

@@ -60,7 +60,7 @@ class Options(C.Structure):
     _fields_ = [("depth_of_field", C.c_int32), ("cache_first_bounce", C.c_int32), ("sort_by_material", C.c_int32),
                 ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
                 ("tile_rows", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):
@@ -117,6 +117,8 @@ def load_library():
     L.ptx_synchronize.restype, L.ptx_synchronize.argtypes = i, [vp]
     L.ptx_read_image.restype, L.ptx_read_image.argtypes = i, [vp, vp]
     L.ptx_device_image.restype, L.ptx_device_image.argtypes = vp, [vp]
+    L.ptx_read_albedo.restype, L.ptx_read_albedo.argtypes = i, [vp, vp]
+    L.ptx_write_denoised_pbo.restype, L.ptx_write_denoised_pbo.argtypes = i, [vp, vp, vp]
     L.ptx_write_pbo.restype, L.ptx_write_pbo.argtypes = i, [vp, i, vp]
     L.ptx_write_pbo_device.restype, L.ptx_write_pbo_device.argtypes = i, [vp, i, vp]
     L.ptx_last_loop_ms.restype, L.ptx_last_loop_ms.argtypes = C.c_double, [vp]
@@ -317,6 +319,17 @@ class Tracer:
     def read_image(self):
         out = np.zeros((self.width * self.height, 3), np.float32)
         _check(self.lib.ptx_read_image(self.h, _ptr(out)), "ptx_read_image")
+        return out
+
+    def read_albedo(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        _check(self.lib.ptx_read_albedo(self.h, _ptr(out)), "ptx_read_albedo")
+        return out
+
+    def denoised_pbo(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(self.width * self.height, 3)
+        out = np.zeros((self.width * self.height, 4), np.uint8)
+        _check(self.lib.ptx_write_denoised_pbo(self.h, _ptr(rgb), _ptr(out)), "ptx_write_denoised_pbo")
         return out
 
     def pbo(self, iteration):

@@ -92,6 +92,8 @@ struct BounceParams {
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
+    int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
+    float *albedo;
     int32_t nbins, maxTiles;
     const int32_t *totals_prev;            // [nbins] stored-path totals of bounce b-1 (n_in = their sum)
     int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]: prefix of the tile inside its workgroup's chunk
@@ -117,7 +119,8 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 // A path that ends adds its radiance to its pixel (finalGather, src/pathtrace.cu:407-416).  Each pixel ends exactly
 // once per iteration, so this is a plain read-modify-write, or -- when several iterations are in flight as
 // segments of one launch -- a plain store into that iteration's buffer.
-__device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3 c) {
+__device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3 c, int apps) {
+    if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
     if (part) {
         float *px = part + (size_t)pix * 3;
         px[0] = c.x; px[1] = c.y; px[2] = c.z;
@@ -125,6 +128,32 @@ __device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3
         float *px = image + (size_t)pix * 3;
         px[0] += c.x; px[1] += c.y; px[2] += c.z;
     }
+}
+
+// Albedo AOV of the apps/src copy (apps/src/pathtrace.cu:412-462): what the first hit of iteration 1 looks like.
+__device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, float *dst) {
+    vec3 a = V3(0.f, 0.f, 0.f);
+    if (hit.t > 0.0f) {
+        const DMaterial &m = sc.mats[hit.mat];
+        const DGeom &geom = sc.geoms[hit.geom];
+        a = V3(m.color[0], m.color[1], m.color[2]);
+        if (geom.type == G_OBJ) {
+            const DTex &kd = geom.tex[0], &ke = geom.tex[2];
+            vec3 emission = V3(0.f, 0.f, 0.f);
+            if (ke.ch) {
+                int pixelID = (int)(hit.v * ke.h) * ke.w + (int)(hit.u * ke.w);
+                emission = V3(texel(sc, ke, pixelID, 0) / 255.f, texel(sc, ke, pixelID, 1) / 255.f, texel(sc, ke, pixelID, 2) / 255.f);
+            }
+            const float eps = 1.1920928955078125e-07f;
+            if (emission.x > eps || emission.y > eps || emission.z > eps) a = scale(emission, 5.0f);
+            else if (kd.ch) {
+                int pixelID = (int)(hit.v * kd.h) * kd.w + (int)(hit.u * kd.w);
+                a = V3(texel(sc, kd, pixelID, 0) / 255.f, texel(sc, kd, pixelID, 1) / 255.f, texel(sc, kd, pixelID, 2) / 255.f);
+            }
+        } else if (m.emittance > 0.0f) a = scale(a, m.emittance);
+        else if (m.hasRefractive > 0.0f) a = V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]);
+    }
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z;
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
@@ -188,7 +217,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
                 Rng rng; rng.seed(iter, in.idx[i], 0);
                 bool ended = scatterRay(p.sc, ps, intersect, h, p.sc.mats[h.mat], rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
-                    deposit(p.image, part, pix, ps.color);
+                    deposit(p.image, part, pix, ps.color, p.apps);
                     alive = false;
                 }
             }
@@ -202,15 +231,17 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
             intersectScene(p.sc, ray, hit);
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
+            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
             if (hit.t > 0.0f) {
                 const DMaterial &m = p.sc.mats[hit.mat];
                 if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
                     vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-                    deposit(p.image, part, pix, c);
+                    deposit(p.image, part, pix, c, p.apps);
                     if (FIRST && p.emit_count) {
+                        const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
                         int k = atomicAdd(p.emit_count, 1);
                         p.emit_pix[k] = pix;
-                        p.emit_rgb[k * 3 + 0] = c.x; p.emit_rgb[k * 3 + 1] = c.y; p.emit_rgb[k * 3 + 2] = c.z;
+                        p.emit_rgb[k * 3 + 0] = cd.x; p.emit_rgb[k * 3 + 1] = cd.y; p.emit_rgb[k * 3 + 2] = cd.z;
                     }
                 } else if (p.traceDepth - p.bounce != 1) {         // :387-390 (last bounce => black)
                     pending = true;
@@ -580,6 +611,7 @@ struct ptx_tracer {
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
     int kmax = 1;                                        // iterations per launch set (segments)
     int uses_uv = 0;
+    float *d_albedo = nullptr;                           // apps variant only: W*H*3
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
@@ -629,7 +661,7 @@ int free_tracer(ptx_tracer *t) {
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
-    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
@@ -702,7 +734,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
         bp.stage = t->soa[1];
         bp.image = t->d_image;
         bp.iter = iter_first; bp.traceDepth = t->traceDepth; bp.bounce = b;
-        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.totals_prev = first ? nullptr : totals(b - 1, 1);
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
@@ -778,7 +810,7 @@ int ptx_device_count(void) {
 void ptx_default_options(ptx_options *o) {
     memset(o, 0, sizeof *o);
     o->depth_of_field = 0; o->cache_first_bounce = 1; o->sort_by_material = 1; o->antialiasing = 1; o->bounding_box = 0;
-    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0;
+    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0; o->apps_variant = 0;
 }
 
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
@@ -908,6 +940,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
     if (kmax > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * (size_t)kmax));
+    if (opt.apps_variant) {
+        HC(hipMalloc(&t->d_albedo, sizeof(float) * 3 * npix));
+        HC(hipMemset(t->d_albedo, 0, sizeof(float) * 3 * npix));
+    }
     HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * kmax));
     t->nsuper = (t->grid + 63) / 64;
     HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid * kmax));
@@ -997,6 +1033,32 @@ int ptx_read_image(ptx_tracer *t, float *host_rgb) {
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipMemcpyAsync(host_rgb, t->d_image, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, hipMemcpyDeviceToHost, t->stream));
     HIPCHECK(hipStreamSynchronize(t->stream));
+    return PTX_OK;
+}
+
+int ptx_read_albedo(ptx_tracer *t, float *host_rgb) {
+    if (!t || !host_rgb) return set_error(PTX_ERR_INVALID, "null argument");
+    if (!t->d_albedo) return set_error(PTX_ERR_INVALID, "the albedo AOV exists only with options.apps_variant = 1");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipMemcpyAsync(host_rgb, t->d_albedo, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, hipMemcpyDeviceToHost, t->stream));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    return PTX_OK;
+}
+
+// sendToGPU + sendDenosiedImageToPBO (apps/src/pathtrace.cu:96-116,673-685): a finished host frame -> 8-bit, no /iter
+int ptx_write_denoised_pbo(ptx_tracer *t, const float *host_rgb, uint8_t *host_rgba) {
+    if (!t || !host_rgb || !host_rgba) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    const size_t n = (size_t)t->cam.resx * t->cam.resy;
+    float *d_in = nullptr; uchar4 *d_out = nullptr;
+    HIPCHECK(hipMalloc(&d_in, sizeof(float) * 3 * n));
+    HIPCHECK(hipMalloc(&d_out, 4 * n));
+    HIPCHECK(hipMemcpyAsync(d_in, host_rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice, t->stream));
+    hipLaunchKernelGGL(k_pbo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, d_out, (int)n, 1, d_in);   // iter = 1: pix / 1
+    hipError_t e = hipMemcpyAsync(host_rgba, d_out, 4 * n, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    hipFree(d_in); hipFree(d_out);
+    if (e != hipSuccess) return set_error(PTX_ERR_HIP, hipGetErrorString(e));
     return PTX_OK;
 }
 

@@ -248,6 +248,8 @@ typedef struct {
     int traceDepth;
     int opt_aa, opt_dof, opt_sort, opt_cache;
     int tile_rows, tile_rank, tile_world;   /* multi-GPU row-tile split (not in the reference): 0,0,1 = whole frame */
+    int apps;                               /* 1 = deltas of the apps/src copy: gather * PI, albedo AOV */
+    float *albedo;
     /* iteration state (pathtrace.cu:91-98) */
     int pixelcount, num_paths, depth;
     float *image;
@@ -277,9 +279,9 @@ void *o_scene_create(int ngeoms, const int *gints3, const float *gmats48, int nm
     return s;
 }
 static void free_iter_state(o_scene *s) {
-    free(s->image); free(s->paths); free(s->paths_tmp); free(s->isects); free(s->isects_tmp);
+    free(s->image); free(s->albedo); free(s->paths); free(s->paths_tmp); free(s->isects); free(s->isects_tmp);
     free(s->first_isects); free(s->flags); free(s->scan); free(s->perm);
-    s->image = NULL; s->paths = s->paths_tmp = NULL; s->isects = s->isects_tmp = s->first_isects = NULL;
+    s->image = NULL; s->albedo = NULL; s->paths = s->paths_tmp = NULL; s->isects = s->isects_tmp = s->first_isects = NULL;
     s->flags = s->scan = s->perm = NULL;
 }
 void o_scene_free(void *h) {
@@ -313,6 +315,12 @@ void o_scene_set_camera(void *h, const int res2[2], const float f19[19], int tra
     memcpy(s->cam.position, f19, sizeof(float) * 19);
     s->traceDepth = traceDepth;
 }
+/* apps/src variant of the reference (the copy its CMake builds): finalGather multiplies by its own
+ * #define PI 3.14159265358f (apps/src/pathtrace.cu:44,508) and the first shade of iteration 1 writes an albedo
+ * AOV (apps/src/pathtrace.cu:412-462). */
+void o_scene_set_apps_variant(void *h, int on) { ((o_scene *)h)->apps = on; }
+float *o_pt_albedo(void *h) { return ((o_scene *)h)->albedo; }
+
 /* Row-tile split used by the multi-GPU driver: this instance traces only the rows y with
  * (y / rows) % world == rank, as its own stream (local stream indices); pixelIndex stays global. */
 void o_scene_set_tile(void *h, int rows, int rank, int world) {
@@ -820,6 +828,7 @@ void o_pt_init(void *h) {
     size_t n = (size_t)(s->pixelcount > 0 ? s->pixelcount : 1);
     size_t nfull = (size_t)s->cam.resx * (size_t)s->cam.resy;
     s->image = (float *)calloc((nfull > 0 ? nfull : 1) * 3, sizeof(float));
+    s->albedo = (float *)calloc((nfull > 0 ? nfull : 1) * 3, sizeof(float));
     s->paths = (o_path *)calloc(n, sizeof(o_path));
     s->paths_tmp = (o_path *)calloc(n, sizeof(o_path));
     s->isects = (o_isect *)calloc(n, sizeof(o_isect));
@@ -912,6 +921,39 @@ int o_pt_bounce(void *h, int iter, int stage_mask) {
     }
     if (stage_mask & 4) {
         double t0 = now_s();
+        if (s->apps && iter == 1 && s->depth == 1) {                        /* apps/src/pathtrace.cu:412-462 */
+            for (int i = 0; i < num_paths; i++) {
+                const o_isect *is = &s->isects[i];
+                float *dst = s->albedo + (size_t)s->paths[i].pixelIndex * 3;
+                if (is->t > 0.0f) {
+                    const o_material *m = &s->mats[is->materialId];
+                    const o_geom *geom = &s->geoms[is->geomId];
+                    st3(dst, ld3(m->color));
+                    if (geom->type == O_OBJ) {
+                        const o_texture *kd = &geom->tex[0], *ke = &geom->tex[2];
+                        v3 emission = V3(0.f, 0.f, 0.f);
+                        if (ke->channels) {
+                            int coordU = (int)(is->texcoord[0] * ke->width), coordV = (int)(is->texcoord[1] * ke->height);
+                            int pixelID = coordV * ke->width + coordU;
+                            emission = V3(texel(ke, pixelID, 0) / 255.f, texel(ke, pixelID, 1) / 255.f, texel(ke, pixelID, 2) / 255.f);
+                        }
+                        if (emission.x > FLT_EPSILON || emission.y > FLT_EPSILON || emission.z > FLT_EPSILON) {
+                            st3(dst, scale3(emission, 5.0f));
+                        } else if (kd->channels) {
+                            int coordU = (int)(is->texcoord[0] * kd->width), coordV = (int)(is->texcoord[1] * kd->height);
+                            int pixelID = coordV * kd->width + coordU;
+                            st3(dst, V3(texel(kd, pixelID, 0) / 255.f, texel(kd, pixelID, 1) / 255.f, texel(kd, pixelID, 2) / 255.f));
+                        }
+                    } else if (m->emittance > 0.0f) {
+                        st3(dst, scale3(ld3(m->color), m->emittance));
+                    } else if (m->hasRefractive > 0.0f) {
+                        st3(dst, ld3(m->speccolor));
+                    }
+                } else {
+                    st3(dst, V3(0.f, 0.f, 0.f));
+                }
+            }
+        }
         for (int i = 0; i < num_paths; i++) shade_one(s, iter, i, &s->isects[i], &s->paths[i]);
         s->secs[2] += now_s() - t0;
     }
@@ -930,7 +972,12 @@ void o_pt_final_gather(void *h) {
     for (int i = 0; i < s->pixelcount; i++) {
         const o_path *p = &s->paths[i];
         float *px = s->image + (size_t)p->pixelIndex * 3;
-        px[0] += p->color[0]; px[1] += p->color[1]; px[2] += p->color[2];
+        if (s->apps) {
+            const float APPS_PI = 3.14159265358f;
+            px[0] += p->color[0] * APPS_PI; px[1] += p->color[1] * APPS_PI; px[2] += p->color[2] * APPS_PI;
+        } else {
+            px[0] += p->color[0]; px[1] += p->color[1]; px[2] += p->color[2];
+        }
     }
     s->secs[5] += now_s() - t0;
 }

@@ -67,6 +67,8 @@ void o_scene_set_faces(void *s, int gi, int nfaces, const float *faces15);
 void o_scene_set_texture(void *s, int gi, int which, int w, int h, int ch, const unsigned char *data);
 void o_scene_set_camera(void *s, const int res2[2], const float f19[19], int traceDepth);
 void o_scene_set_options(void *s, int aa, int dof, int sort, int cache);
+void o_scene_set_apps_variant(void *s, int on);   /* apps/src deltas: gather * PI, albedo AOV at iter 1 */
+float *o_pt_albedo(void *s);
 void o_scene_set_tile(void *s, int rows, int rank, int world);   /* multi-GPU row tiles; 0,0,1 = whole frame */
 
 /* per-function entry points; same record layouts as oracle/ref_driver.cpp */

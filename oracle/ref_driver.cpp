@@ -58,14 +58,15 @@ struct RefOptions {
     int depth_of_field;  // DEPTH_OF_FIELD    (:36) default 0
     int sort_by_material;// SORT_BY_MATERIAL  (:38) default 1
     int cache_first;     // CACHE_FIRST_BOUNCE(:37) default 1
+    int apps;            // 1 = the apps/src copy's deltas: finalGather * PI (apps/src/pathtrace.cu:508) + albedo AOV (:412-462)
 };
 
 struct RefState {
     Scene *scene = nullptr;
     std::vector<Geom> geoms;              // with host pointers patched in (pathtraceInit :111-140)
     std::vector<Texture> empty;
-    RefOptions opt{1, 0, 1, 1};
-    std::vector<glm::vec3> image;
+    RefOptions opt{1, 0, 1, 1, 0};
+    std::vector<glm::vec3> image, albedo;
     std::vector<PathSegment> paths;
     std::vector<ShadeableIntersection> isects, first_isects;
     int num_paths = 0, depth = 0, pixelcount = 0;
@@ -220,8 +221,11 @@ void ref_apply_runcuda_camera(void *h) {
 
 void ref_set_options(void *h, int aa, int dof, int sort, int cache) {
     RefState *st = (RefState *)h;
-    st->opt = RefOptions{aa, dof, sort, cache};
+    st->opt = RefOptions{aa, dof, sort, cache, st->opt.apps};
 }
+
+void ref_set_apps_variant(void *h, int on) { ((RefState *)h)->opt.apps = on; }
+float *ref_pt_albedo(void *h) { return (float *)((RefState *)h)->albedo.data(); }
 
 // ---- per-function known-answer entry points (call the reference functions directly) ----------------
 // rays: o(3) d(3) per ray.  out per ray: t, point(3), normal(3), uv(2), outside  = 10 floats
@@ -375,6 +379,7 @@ void ref_pt_init(void *h) {
     const Camera &cam = st->scene->state.camera;
     st->pixelcount = cam.resolution.x * cam.resolution.y;
     st->image.assign(st->pixelcount, glm::vec3(0.f));
+    st->albedo.assign(st->pixelcount, glm::vec3(0.f));
     st->paths.assign(st->pixelcount, PathSegment());
     ShadeableIntersection z; memset(&z, 0, sizeof z);
     st->isects.assign(st->pixelcount, z);
@@ -429,6 +434,48 @@ int ref_pt_bounce(void *h, int iter, int stage_mask) {
         st->depth++;
     }
     if (stage_mask & 4) {
+        if (st->opt.apps && iter == 1 && st->depth == 1) {
+            // albedo AOV of the apps/src copy (apps/src/pathtrace.cu:412-462), first shade of the first iteration
+            for (int i = 0; i < num_paths; i++) {
+                const ShadeableIntersection &intersection = st->isects[i];
+                glm::vec3 &dst = st->albedo[st->paths[i].pixelIndex];
+                if (intersection.t > 0.0f) {
+                    Material material = st->scene->materials[intersection.materialId];
+                    glm::vec3 materialColor = material.color;
+                    dst = materialColor;
+                    Geom geom = st->geoms[intersection.geomId];
+                    if (geom.type == OBJ) {
+                        glm::vec3 emission(0.0f);
+                        if (geom.ke.channels) {
+                            int coordU = (int)(intersection.texcoord.x * geom.ke.width);
+                            int coordV = (int)(intersection.texcoord.y * geom.ke.height);
+                            int pixelID = coordV * geom.ke.width + coordU;
+                            unsigned int colR = (unsigned int)geom.ke.image[pixelID * geom.ke.channels];
+                            unsigned int colG = (unsigned int)geom.ke.image[pixelID * geom.ke.channels + 1];
+                            unsigned int colB = (unsigned int)geom.ke.image[pixelID * geom.ke.channels + 2];
+                            emission = glm::vec3(colR / 255.f, colG / 255.f, colB / 255.f);
+                        }
+                        if (emission.x > FLT_EPSILON || emission.y > FLT_EPSILON || emission.z > FLT_EPSILON) {
+                            dst = (emission * 5.0f);
+                        } else if (geom.kd.channels) {
+                            int coordU = (int)(intersection.texcoord.x * geom.kd.width);
+                            int coordV = (int)(intersection.texcoord.y * geom.kd.height);
+                            int pixelID = coordV * geom.kd.width + coordU;
+                            unsigned int colR = (unsigned int)geom.kd.image[pixelID * geom.kd.channels];
+                            unsigned int colG = (unsigned int)geom.kd.image[pixelID * geom.kd.channels + 1];
+                            unsigned int colB = (unsigned int)geom.kd.image[pixelID * geom.kd.channels + 2];
+                            dst = glm::vec3(colR / 255.f, colG / 255.f, colB / 255.f);
+                        }
+                    } else if (material.emittance > 0.0f) {
+                        dst = materialColor * material.emittance;
+                    } else if (material.hasRefractive > 0.0f) {
+                        dst = material.specular.color;
+                    }
+                } else {
+                    dst = glm::vec3(0.0f);
+                }
+            }
+        }
         for (int i = 0; i < num_paths; i++) shade_one(st, iter, i, st->isects[i], st->paths[i], st->depth);
     }
     if (stage_mask & 8) {
@@ -441,7 +488,11 @@ int ref_pt_bounce(void *h, int iter, int stage_mask) {
 
 void ref_pt_final_gather(void *h) {
     RefState *st = (RefState *)h;
-    for (int i = 0; i < st->pixelcount; i++) st->image[st->paths[i].pixelIndex] += st->paths[i].color;
+    const float APPS_PI = 3.14159265358f;        // apps/src/pathtrace.cu:44
+    for (int i = 0; i < st->pixelcount; i++) {
+        if (st->opt.apps) st->image[st->paths[i].pixelIndex] += st->paths[i].color * APPS_PI;
+        else st->image[st->paths[i].pixelIndex] += st->paths[i].color;
+    }
 }
 
 // full iteration = pathtrace(pbo, frame, iter) without the PBO

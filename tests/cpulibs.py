@@ -153,6 +153,18 @@ class _Tracer:
         addr = self._f("pt_isects")(self.h)
         return np.ctypeslib.as_array((C.c_char * (32 * n)).from_address(addr)).view(ISECT_DTYPE).copy()
 
+    def set_apps_variant(self, on):
+        fn = self._f("set_apps_variant") if self.prefix == "ref_" else self.lib.o_scene_set_apps_variant
+        fn.argtypes = [vp, C.c_int]
+        fn(self.h, int(on))
+
+    def albedo(self):
+        n = self.framepixels()
+        fn = self._f("pt_albedo")
+        fn.restype, fn.argtypes = vp, [vp]
+        addr = fn(self.h)
+        return np.ctypeslib.as_array((C.c_float * (3 * n)).from_address(addr)).reshape(n, 3).copy()
+
     def image(self):
         n = self.framepixels()
         addr = self._f("pt_image")(self.h)

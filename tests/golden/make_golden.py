@@ -241,6 +241,16 @@ def main():
         out["pbo_spp16"] = R.pbo(16)
         np.savez_compressed(os.path.join(HERE, "render_%s.npz" % tag), **out)
 
+    # ---- apps/src variant (x PI gather + albedo AOV): textured stand-in scene and the glass scene ------------------
+    for tag, text, cwd in [("apps_ship", ship_text((96, 54), 8), REPO_SCENES), ("apps_glass", ref_text("cornellGlass.txt", (64, 64), 8), os.path.join(REFERENCE_ROOT, "scenes"))]:
+        R.load_text(text, cwd=cwd)
+        R.apply_runcuda_camera()
+        R.set_apps_variant(1)
+        R.pt_init()
+        for it in (1, 2, 3):
+            R.iterate(it)
+        np.savez_compressed(os.path.join(HERE, "render_%s.npz" % tag), image_spp3=R.image(), albedo=R.albedo(), counts_it3=R.live_counts())
+
     # ---- full-resolution live counts of iteration 1 (SURVEY 8(c) anchors, regenerated) ---------------------------
     full = {}
     for tag, name, res, depth, opt in [("c2", "cornell.txt", (800, 800), 8, dict(aa=0, dof=0, sort=1, cache=1)),

@@ -342,3 +342,25 @@ def test_headless_driver(gpu_product, tmp_path):
         T.render(1, 3)
         want = T.read_image().reshape(48, 64, 3) / np.float32(3)
     assert np.array_equal(frame, want)
+
+
+@pytest.mark.parametrize("tag,scene,res", [("apps_ship", "cornellSpaceship.txt", (96, 54)), ("apps_glass", "cornellGlass.txt", (64, 64))])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_apps_variant_on_device(gpu_product, O, tag, scene, res, batch):
+    """apps_variant = 1 reproduces the apps/src copy of the reference: image (x PI) and albedo AOV equal the golden
+    vectors from the reference build and the oracle; the denoised-frame preview path clamps like sendDenosiedImageToPBO."""
+    r = golden("render_%s.npz" % tag)
+    s, T = make_pair(gpu_product, O, scene, res, 8, apps_variant=1, batch=batch)
+    O.set_apps_variant(1); O.pt_init()
+    for it in (1, 2, 3):
+        O.iterate(it)
+    T.render(1, 3)
+    img, alb = T.read_image(), T.read_albedo()
+    assert beq(img, O.image()) and beq(alb, O.albedo())
+    assert np.array_equal(img, r["image_spp3"]) and np.array_equal(alb, r["albedo"])
+    frame = (img / np.float32(3)).astype(np.float32)
+    pbo = T.denoised_pbo(frame)
+    want = np.clip((frame.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    assert np.array_equal(pbo[:, :3], want) and not pbo[:, 3].any()
+    T.close()
+    O.set_apps_variant(0)

@@ -174,3 +174,19 @@ def test_stream_compaction_cpu(O):
         for with_scan in (False, True):
             out, cnt = O.sc_compact(a, with_scan)
             assert cnt == int((a != 0).sum()) and np.array_equal(out, a[a != 0])
+
+
+@pytest.mark.parametrize("tag,scene,res", [("apps_ship", "cornellSpaceship", (96, 54)), ("apps_glass", "cornellGlass", (64, 64))])
+def test_apps_variant(O, tag, scene, res):
+    """The apps/src copy of the reference: finalGather * PI and the albedo AOV of iteration 1."""
+    r = golden("render_%s.npz" % tag)
+    g = golden("loader_%s.npz" % scene)
+    d = dump_from_golden(g, cam="cam_floats")
+    cf = d["cam_floats"]
+    d["cam_floats"] = O.camera_from_loader(res[0], res[1], float(cf[16]), cf[0:3], cf[3:6], cf[9:12])
+    ci = d["cam_ints"].copy(); ci[0], ci[1], ci[3] = res[0], res[1], 8
+    d["cam_ints"] = ci
+    O.create(d); O.apply_runcuda_camera(); O.set_apps_variant(1); O.pt_init()
+    for it in (1, 2, 3):
+        O.iterate(it)
+    assert beq(O.image(), r["image_spp3"]) and beq(O.albedo(), r["albedo"]) and beq(O.live_counts(), r["counts_it3"])
