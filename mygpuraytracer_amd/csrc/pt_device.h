@@ -206,12 +206,45 @@ struct DScene {
                                         // triangle test starts with, done once at upload: same IEEE results)
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
-    int32_t tri_lds;                    // != 0: the kernel has staged tri9 at the start of its dynamic LDS (pt_lds)
+    int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS
+                                        // (pt_lds): tri9 [ntri*9], faces [ntri*15], materials [nmats*11]
     int32_t ntri;
 };
 
-// dynamic LDS of the kernels that use this header: [tri9 copy when sc.tri_lds][per-tile ranking histogram]
+PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri * 24 + sc.nmats * 11 + 3) & ~3; }
+
+// dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]
 extern __shared__ __attribute__((aligned(16))) int32_t pt_lds[];
+
+// Copies the scene tables into LDS (call from every thread of the workgroup, then __syncthreads()).
+__device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int nthreads) {
+    float *l = reinterpret_cast<float *>(pt_lds);
+    const int n9 = sc.ntri * 9, n15 = sc.ntri * 15, nm = sc.nmats * 11;
+    for (int k = tid; k < n9; k += nthreads) l[k] = sc.tri9[k];
+    for (int k = tid; k < n15; k += nthreads) l[n9 + k] = sc.faces[k];
+    const float *m = reinterpret_cast<const float *>(sc.mats);
+    for (int k = tid; k < nm; k += nthreads) l[n9 + n15 + k] = m[k];
+}
+
+// struct Material of material `id` (per-lane id: from LDS when staged, else global memory)
+PT_DEV DMaterial getMaterial(const DScene &sc, int id) {
+    DMaterial m;
+    if (sc.tri_lds) {
+        const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + id * 11;
+        m.color[0] = l[0]; m.color[1] = l[1]; m.color[2] = l[2]; m.exponent = l[3];
+        m.speccolor[0] = l[4]; m.speccolor[1] = l[5]; m.speccolor[2] = l[6];
+        m.hasReflective = l[7]; m.hasRefractive = l[8]; m.ior = l[9]; m.emittance = l[10];
+    } else {
+        m = sc.mats[id];
+    }
+    return m;
+}
+// word k of the 15-float record (3 x pos xyz, uv) of triangle `face` (global index)
+PT_DEV float faceWord(const DScene &sc, int face, int k) {
+    if (sc.tri_lds) return reinterpret_cast<const float *>(pt_lds)[sc.ntri * 9 + face * 15 + k];
+    return sc.faces[(size_t)face * 15 + k];
+}
+PT_DEV vec3 faceVec(const DScene &sc, int face, int k) { return V3(faceWord(sc, face, k), faceWord(sc, face, k + 1), faceWord(sc, face, k + 2)); }
 
 enum { G_SPHERE = 0, G_CUBE = 1, G_TRIANGLE = 2, G_OBJ = 3 };
 
@@ -343,7 +376,6 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
     q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
     float tmin = 3.402823466e+38f;     // FLT_MAX
     int nearest = -1;
-    const float *__restrict__ faces = sc.faces + (size_t)geom.faceStart * 15;
     for (int j = 0; j < geom.faceCount; j++) {
         vec3 v0, e1, e2;
         if (sc.tri_lds) {             // broadcast ds_reads: every lane reads the same triangle
@@ -355,16 +387,16 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
         }
         float b0, b1;
         if (rayTriangle(q.o, q.d, v0, e1, e2, b0, b1)) {
-            const float *__restrict__ tri = faces + (size_t)j * 15;
-            vec3 p1 = ld3(tri + 5), p2 = ld3(tri + 10);
+            const int f = geom.faceStart + j;
+            vec3 p1 = faceVec(sc, f, 5), p2 = faceVec(sc, f, 10);
             float w = 1 - b0 - b1;
             vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
             float t = length(sub(q.o, p));          // glm::distance(p, q.origin)
             if (t < tmin) {
                 tmin = t;
                 nearest = j;
-                c.u = (w * tri[3] + b0 * tri[8]) + b1 * tri[13];
-                c.v = (w * tri[4] + b0 * tri[9]) + b1 * tri[14];
+                c.u = (w * faceWord(sc, f, 3) + b0 * faceWord(sc, f, 8)) + b1 * faceWord(sc, f, 13);
+                c.v = (w * faceWord(sc, f, 4) + b0 * faceWord(sc, f, 9)) + b1 * faceWord(sc, f, 14);
             }
         }
     }
@@ -375,7 +407,10 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
 // geometric normal (+ optional tangent-space bump map) of the chosen face, src/intersections.h:237-279
 // geoN = the unperturbed normal (the reference derives its unused `outside` flag from it, :243)
 PT_DEV vec3 meshNormal(const DScene &sc, const DGeom &geom, const Cand &c, vec3 &geoN) {
-    const float *__restrict__ tri = sc.faces + ((size_t)geom.faceStart + c.face) * 15;
+    const int fi = geom.faceStart + c.face;
+    float tri[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) tri[k] = faceWord(sc, fi, k);
     vec3 e1 = sub(ld3(tri + 5), ld3(tri));
     vec3 e2 = sub(ld3(tri + 10), ld3(tri));
     vec3 objN = normalize(cross(e1, e2));
@@ -419,6 +454,21 @@ struct Hit {
     int32_t geom, mat;
 };
 
+// Header of geom i (transform, inverseTransform, type, material, face range) through the SCALAR memory path: the
+// index is wave-uniform and the table is immutable while a kernel runs, so reading it as constant address space
+// lets the compiler use s_load and keep the matrices in SGPRs instead of one VGPR copy per lane.
+PT_DEV void loadGeomHead(const DGeom *geoms, int i, DGeom &g) {
+    typedef const __attribute__((address_space(4))) float cfloat;
+    typedef const __attribute__((address_space(4))) int32_t cint;
+    cfloat *pf = (cfloat *)(const float *)geoms[i].xf;
+#pragma unroll
+    for (int k = 0; k < 16; k++) g.xf[k] = pf[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g.inv[k] = pf[16 + k];
+    cint *pi = (cint *)(const int32_t *)&geoms[i].type;
+    g.type = pi[0]; g.materialid = pi[1]; g.faceStart = pi[2]; g.faceCount = pi[3];
+}
+
 // body of computeIntersections, src/pathtrace.cu:270-343: nearest t > 0 over all geoms, lowest index wins ties.
 // A miss leaves materialId = 0 (the reference's full-frame memset, :501), which is what the material sort sees.
 PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
@@ -429,7 +479,8 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
     best.axis = -1; best.sgn = 0.f; best.objP = V3(0.f, 0.f, 0.f); best.outside = true; best.face = -1; best.u = best.v = 0.f;
     float tmp_u = 0.f, tmp_v = 0.f;          // the reference's tmp_uv survives from one mesh to the next geom
     for (int i = 0; i < sc.ngeoms; i++) {
-        const DGeom &geom = sc.geoms[i];
+        DGeom geom;
+        loadGeomHead(sc.geoms, i, geom);
         float t = 0.f;
         Cand c;
         c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = tmp_u; c.v = tmp_v;

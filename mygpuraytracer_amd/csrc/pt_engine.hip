@@ -46,7 +46,10 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
             return set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-constexpr int TILE = 256;          // paths per tile = threads per workgroup (4 waves of 64)
+#ifndef PT_TILE
+#define PT_TILE 256
+#endif
+constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
@@ -134,7 +137,7 @@ __device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3
 __device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, float *dst) {
     vec3 a = V3(0.f, 0.f, 0.f);
     if (hit.t > 0.0f) {
-        const DMaterial &m = sc.mats[hit.mat];
+        const DMaterial m = getMaterial(sc, hit.mat);
         const DGeom &geom = sc.geoms[hit.geom];
         a = V3(m.color[0], m.color[1], m.color[2]);
         if (geom.type == G_OBJ) {
@@ -159,20 +162,17 @@ __device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, f
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 template <bool FIRST>
 __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
-    // dynamic LDS (pt_lds): [tri9 table when staged][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
+    // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = p.nbins;
-    const int triWords = p.sc.tri_lds ? ((p.sc.ntri * 9 + 3) & ~3) : 0;
+    const int triWords = p.sc.tri_lds ? sceneLdsWords(p.sc) : 0;
     int32_t *lds = pt_lds + triWords;
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
     int32_t *rec = toff + nb + 1;                                   // [17][TILE] record transpose buffer
-    if (p.sc.tri_lds) {
-        float *t9 = reinterpret_cast<float *>(pt_lds);
-        for (int k = tid; k < p.sc.ntri * 9; k += TILE) t9[k] = p.sc.tri9[k];
-    }
+    if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
     __syncthreads();
     const int seg = blockIdx.y;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
                 int mg = in.mg[i];
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
                 Rng rng; rng.seed(iter, in.idx[i], 0);
-                bool ended = scatterRay(p.sc, ps, intersect, h, p.sc.mats[h.mat], rng);
+                bool ended = scatterRay(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
                     deposit(p.image, part, pix, ps.color, p.apps);
                     alive = false;
@@ -232,9 +232,11 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
             intersectScene(p.sc, ray, hit);
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
             if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
+            bool lit = false;
             if (hit.t > 0.0f) {
-                const DMaterial &m = p.sc.mats[hit.mat];
+                const DMaterial m = getMaterial(p.sc, hit.mat);
                 if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
+                    lit = true;
                     vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
                     deposit(p.image, part, pix, c, p.apps);
                     if (FIRST && p.emit_count) {
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
             }
             // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
             // in batched mode the path's slot of the per-iteration buffer must still be written
-            if (part && !pending && !(hit.t > 0.0f && p.sc.mats[hit.mat].emittance > 0.0f)) {
+            if (part && !pending && !lit) {
                 float *px = part + (size_t)pix * 3;
                 px[0] = 0.f; px[1] = 0.f; px[2] = 0.f;
             }
@@ -675,7 +677,7 @@ int free_tracer(ptx_tracer *t) {
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
 int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
-    const int triWords = t->tri_lds ? ((t->ntri * 9 + 3) & ~3) : 0;
+    const int triWords = t->tri_lds ? ((t->ntri * 24 + t->nmats * 11 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb + 2 * nb + 1 + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
@@ -861,7 +863,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     auto fail = [&](int code) { free_tracer(t); return code; };
 #define HC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(PTX_ERR_HIP); } } while (0)
     HC(hipGetDeviceProperties(&prop, dev));
-    t->grid = std::min(t->maxTiles, prop.multiProcessorCount * 8);
+    t->grid = std::min(t->maxTiles, prop.multiProcessorCount * (2048 / TILE));
     if (t->grid < 1) t->grid = 1;
     if (stream) { t->stream = (hipStream_t)stream; t->own_stream = false; }
     else { HC(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)); t->own_stream = true; }
@@ -900,7 +902,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
     }
     // the table goes to LDS when it leaves room for at least 2 workgroups per CU (160 KB LDS, ~19 KB of sort buffers)
-    t->tri_lds = (t->ntri > 0 && (size_t)t->ntri * 36 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    t->tri_lds = (((size_t)t->ntri * 24 + (size_t)nmaterials * 11) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
     if (hfaces.empty()) hfaces.resize(15, 0.f);
     if (htex.empty()) htex.resize(16, 0);
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
