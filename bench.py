@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on a box with fewer GPUs than ranks: the frame is then reduced through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -69,18 +71,38 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     n_gpus = world
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+
+    def reduce_frame(img):
+        """One reduce(SUM) of the accumulation buffer to rank 0: RCCL on the device buffer, or (gloo rehearsal) via host."""
+        if args.backend == "nccl":
+            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            h = img.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                img.copy_(h)
+
+    def all_reduce_scalar(value, dtype, op):
+        tt = torch.tensor([value], dtype=dtype, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=op)
+        return tt.item()
 
     scene = pt.Scene(os.path.join(ROOT, "scenes", SCENE), res=RES, depth=DEPTH)
     scene.apply_runcuda_camera()
     W, H = RES
     image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
-    kw = dict(device=local_rank)
+    kw = dict(device=dev_index)
     if world > 1:
         kw.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
     T = pt.Tracer(scene, external_image_ptr=image.data_ptr(), **kw)
@@ -94,26 +116,22 @@ def main():
     T.render(1, args.warmup)
     T.synchronize()
     if world > 1:                                   # warm the collective too
-        dist.reduce(image.clone(), dst=0, op=dist.ReduceOp.SUM)
+        reduce_frame(image.clone())
     rays0 = T.stats()["rays_total"]
     barrier()
     t0 = time.perf_counter()
     T.render(args.warmup + 1, args.steps)           # EXACTLY K steps, enqueued back to back on the tracer's stream
     T.synchronize()
     if world > 1:                                   # one RCCL reduce of the accumulation buffer per run
-        dist.reduce(image, dst=0, op=dist.ReduceOp.SUM)
+        reduce_frame(image)
     barrier()
     dt = time.perf_counter() - t0
     st = T.stats()
     rays = st["rays_total"] - rays0
     loop_ms = T.last_loop_ms()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        rr = torch.tensor([rays], dtype=torch.int64, device=device)
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays = int(rr.item())
+        dt = float(all_reduce_scalar(dt, torch.float64, dist.ReduceOp.MAX))
+        rays = int(all_reduce_scalar(rays, torch.int64, dist.ReduceOp.SUM))
 
     # roofline leg: the same K steps again with hipEvents around every launch (on the tracer's stream)
     T.set_kernel_timing(True)

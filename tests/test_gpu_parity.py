@@ -364,3 +364,73 @@ def test_apps_variant_on_device(gpu_product, O, tag, scene, res, batch):
     assert np.array_equal(pbo[:, :3], want) and not pbo[:, 3].any()
     T.close()
     O.set_apps_variant(0)
+
+
+def _scene_from_text(pt, text, tmp_path, res=None, depth=None):
+    f = tmp_path / "scene.txt"
+    f.write_text(text)
+    s = pt.Scene(str(f), base_dir=os.path.join(ROOT, "scenes"), res=res, depth=depth)
+    s.apply_runcuda_camera()
+    return s
+
+
+def _vs_oracle(pt, O, s, iters=3, **opt):
+    d = s.dump()
+    O.set_libm(1); O.create(d, d["textures"])
+    O.set_options(aa=opt.get("antialiasing", 1), dof=opt.get("depth_of_field", 0), sort=opt.get("sort_by_material", 1), cache=opt.get("cache_first_bounce", 1))
+    O.pt_init()
+    with pt.Tracer(s, **opt) as T:
+        for it in range(1, iters + 1):
+            O.iterate(it)
+        T.render(1, iters)
+        assert beq(T.read_image(), O.image())
+        assert T.stats()["rays_per_bounce"][: len(O.live_counts())] == O.live_counts().tolist()
+        return T.read_image()
+
+
+CAMERA_BLOCK = "CAMERA\nRES 64 64\nFOVY 45\nITERATIONS 10\nDEPTH 8\nFILE edge\nEYE 0.0 5 10.5\nLOOKAT 0 5 0\nUP 0 1 0\n\n"
+MAT = "MATERIAL %d\nRGB %g %g %g\nSPECEX 0\nSPECRGB %g %g %g\nREFL %g\nREFR %g\nREFRIOR %g\nEMITTANCE %g\n\n"
+
+
+def test_edge_empty_scene(gpu_product, O, tmp_path):
+    """No geometry at all: every ray misses at bounce 0, the image stays black, nothing is stored."""
+    s = _scene_from_text(gpu_product, MAT % (0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 5) + CAMERA_BLOCK, tmp_path)
+    img = _vs_oracle(gpu_product, O, s)
+    assert not img.any()
+
+
+@pytest.mark.parametrize("res,depth", [((1, 1), 8), ((37, 23), 8), ((257, 3), 3), ((64, 64), 1), ((300, 200), 2)])
+def test_edge_ragged_sizes_and_depths(gpu_product, O, res, depth):
+    """Frames that are not a multiple of the 256-path tile, a single pixel, and the shortest legal path (depth 1:
+    only lights seen directly contribute)."""
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt"), res=res, depth=depth)
+    s.apply_runcuda_camera()
+    _vs_oracle(gpu_product, O, s)
+    _vs_oracle(gpu_product, O, s, batch=1, sort_by_material=0)
+
+
+def test_edge_many_materials(gpu_product, O, tmp_path):
+    """More material bins (70) than lanes in a wave, mirrors / glass / lights / diffuse interleaved, rotated and scaled
+    cubes and spheres: the per-bin ranking, the chunk prefixes and the segment bases all get exercised."""
+    rng = np.random.default_rng(12)
+    text = ""
+    nm = 70
+    for m in range(nm):
+        kind = m % 7
+        rgb = rng.uniform(0.2, 0.95, 3)
+        refl, refr, ior, emit = (1, 0, 0, 0) if kind == 3 else (0, 1, 1.3 + 0.01 * m, 0) if kind == 5 else (0, 0, 0, 4 if kind == 0 else 0)
+        text += MAT % ((m,) + tuple(rgb) + tuple(rgb[::-1]) + (refl, refr, ior, emit))
+    text += CAMERA_BLOCK
+    text += "OBJECT 0\ncube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 12 .01 12\n\n"
+    text += "OBJECT 1\ncube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 8 .3 8\n\n"
+    for k in range(2, 40):
+        typ = "sphere" if k % 2 else "cube"
+        pos = rng.uniform([-4.5, 0.5, -4.5], [4.5, 8.5, 2.0])
+        rot = rng.uniform(0, 90, 3)
+        sc = rng.uniform(0.4, 1.6, 3)
+        text += "OBJECT %d\n%s\nmaterial %d\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g\n\n" % ((k, typ, int(rng.integers(0, nm))) + tuple(pos) + tuple(rot) + tuple(sc))
+    s = _scene_from_text(gpu_product, text, tmp_path, res=(120, 90), depth=6)
+    assert s.num_materials == 70 and s.num_geoms == 40
+    _vs_oracle(gpu_product, O, s, iters=4)
+    _vs_oracle(gpu_product, O, s, iters=4, batch=1)
+    _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1, antialiasing=0)
