@@ -94,7 +94,9 @@ typedef struct ptx_options {
     int32_t apps_variant;        /* 1 = behave like the apps/src copy of the reference (the one its CMake builds):
                                     finalGather adds color * PI (apps/src/pathtrace.cu:508) and iteration 1 fills an
                                     albedo AOV (apps/src/pathtrace.cu:412-462, ptx_read_albedo) */
-    int32_t reserved[4];
+    int32_t no_cull;             /* 1 = every ray tests every geom (the reference's loop) instead of per-lane candidate
+                                    lists from conservative world boxes; results are identical either way */
+    int32_t reserved[3];
 } ptx_options;
 
 typedef struct ptx_stats {

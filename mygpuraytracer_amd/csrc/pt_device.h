@@ -207,11 +207,16 @@ struct DScene {
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
     int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS
-                                        // (pt_lds): tri9 [ntri*9], faces [ntri*15], materials [nmats*11]
+                                        // (pt_lds): tri9 [ntri*9], faces [ntri*15], materials [nmats*11], gtab [ngeoms*40]
     int32_t ntri;
+    const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
+                                        // invTranspose rows 0-2 (12), type, materialid, faceStart, faceCount
+    const float *__restrict__ aabb;     // 6 floats per geom: conservative world-space box (min xyz, max xyz), or NULL
+    int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
-PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri * 24 + sc.nmats * 11 + 3) & ~3; }
+PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri * 24 + sc.nmats * 11 + sc.ngeoms * 40 + 3) & ~3; }
+constexpr int GTAB_WORDS = 40;
 
 // dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]
 extern __shared__ __attribute__((aligned(16))) int32_t pt_lds[];
@@ -224,6 +229,8 @@ __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int n
     for (int k = tid; k < n15; k += nthreads) l[n9 + k] = sc.faces[k];
     const float *m = reinterpret_cast<const float *>(sc.mats);
     for (int k = tid; k < nm; k += nthreads) l[n9 + n15 + k] = m[k];
+    const int ng = sc.ngeoms * GTAB_WORDS;
+    for (int k = tid; k < ng; k += nthreads) l[n9 + n15 + nm + k] = sc.gtab[k];
 }
 
 // struct Material of material `id` (per-lane id: from LDS when staged, else global memory)
@@ -471,7 +478,10 @@ PT_DEV void loadGeomHead(const DGeom *geoms, int i, DGeom &g) {
 
 // body of computeIntersections, src/pathtrace.cu:270-343: nearest t > 0 over all geoms, lowest index wins ties.
 // A miss leaves materialId = 0 (the reference's full-frame memset, :501), which is what the material sort sees.
+PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h);
+
 PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
+    if (sc.cull) { intersectSceneCull(sc, ray, h); return; }
     float t_min = 3.402823466e+38f;
     h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
     int hit_geom_index = -1;
@@ -504,6 +514,159 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
         if (geom.type == G_CUBE) h.n = boxNormal(geom, best);
         else if (geom.type == G_SPHERE) h.n = sphereNormal(geom, best);
         else { vec3 geoN; h.n = meshNormal(sc, geom, best, geoN); }
+    }
+}
+
+// ---- per-lane candidate lists -------------------------------------------------------------------------------------
+// computeIntersections asks every ray about every geom.  In a wave of incoherent rays each lane really needs two or
+// three of them, but the wave pays for all.  Here every lane first collects the geoms whose conservative world-space
+// box its ray can reach (a miss of that box implies a miss of the exact test: the box is inflated far beyond fp32
+// error, see make_world_aabb in pt_engine.hip), then the wave loops "each lane takes ITS next cube or sphere" with the
+// geom tables gathered per lane from LDS.  The exact tests and their arithmetic are unchanged, so is the result:
+// nearest t > 0, lowest geom index on ties (the reference's strict `t_min > t` in index order).
+
+// xyz of mat4*vec4 for a matrix stored as 3 rows of 4 (same products and sums as multiplyMV)
+PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
+    vec3 o;
+    o.x = (r[0] * v.x + r[1] * v.y) + (r[2] * v.z + r[3] * w);
+    o.y = (r[4] * v.x + r[5] * v.y) + (r[6] * v.z + r[7] * w);
+    o.z = (r[8] * v.x + r[9] * v.y) + (r[10] * v.z + r[11] * w);
+    return o;
+}
+
+PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h) {
+    const float *lds_f = reinterpret_cast<const float *>(pt_lds);
+    const float *gtab = lds_f + sc.ntri * 24 + sc.nmats * 11;
+    // conservative slab test against every geom's world box (uniform index: the boxes come through the scalar path)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat *ab = (cfloat *)sc.aabb;
+    const float tiny = 1e-20f;
+    const float ddx = __builtin_fabsf(ray.d.x) < tiny ? __builtin_copysignf(tiny, ray.d.x) : ray.d.x;
+    const float ddy = __builtin_fabsf(ray.d.y) < tiny ? __builtin_copysignf(tiny, ray.d.y) : ray.d.y;
+    const float ddz = __builtin_fabsf(ray.d.z) < tiny ? __builtin_copysignf(tiny, ray.d.z) : ray.d.z;
+    const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
+    uint32_t prim_mask = 0, mesh_mask = 0;
+    for (int i = 0; i < sc.ngeoms; i++) {
+        const float x0 = (ab[i * 6 + 0] - ray.o.x) * ix, x1 = (ab[i * 6 + 3] - ray.o.x) * ix;
+        const float y0 = (ab[i * 6 + 1] - ray.o.y) * iy, y1 = (ab[i * 6 + 4] - ray.o.y) * iy;
+        const float z0 = (ab[i * 6 + 2] - ray.o.z) * iz, z1 = (ab[i * 6 + 5] - ray.o.z) * iz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const bool culled = (tf < tn) || (tf < 0.0f);          // any NaN => not culled
+        const int type = __float_as_int(((cfloat *)sc.gtab)[i * GTAB_WORDS + 36]);
+        if (!culled) {
+            if (type == G_OBJ) mesh_mask |= 1u << i;
+            else if (type == G_CUBE || type == G_SPHERE) prim_mask |= 1u << i;
+        }
+    }
+    float t_min = 3.402823466e+38f;
+    int best_g = -1;
+    Cand best;
+    best.axis = -1; best.sgn = 0.f; best.objP = V3(0.f, 0.f, 0.f); best.outside = true; best.face = -1; best.u = best.v = 0.f;
+    // cubes and spheres: every lane works on its own next candidate
+    while (__any(prim_mask != 0)) {
+        if (prim_mask != 0) {
+            const int g = __ffs((int)prim_mask) - 1;
+            prim_mask &= prim_mask - 1;
+            const float *G = gtab + g * GTAB_WORDS;
+            float inv[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) inv[k] = G[k];
+            const int type = __float_as_int(G[36]);
+            Ray q;
+            q.o = mulRows(inv, ray.o, 1.0f);
+            q.d = normalize(mulRows(inv, ray.d, 0.0f));
+            Cand c;
+            c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = c.v = 0.f;
+            bool hit = false;
+            if (type == G_CUBE) {                      // boxIntersectionTest, src/intersections.h:54-84
+                float tmin = -1e38f, tmax = 1e38f;
+                int tmin_axis = -1, tmax_axis = -1;
+                float tmin_s = 0.f, tmax_s = 0.f;
+                const float qo[3] = {q.o.x, q.o.y, q.o.z};
+                const float qd[3] = {q.d.x, q.d.y, q.d.z};
+#pragma unroll
+                for (int xyz = 0; xyz < 3; ++xyz) {
+                    float t1 = (-0.5f - qo[xyz]) / qd[xyz];
+                    float t2 = (+0.5f - qo[xyz]) / qd[xyz];
+                    float ta = fmin_glm(t1, t2);
+                    float tb = fmax_glm(t1, t2);
+                    float ns = t2 < t1 ? +1.f : -1.f;
+                    if (ta > 0 && ta > tmin) { tmin = ta; tmin_axis = xyz; tmin_s = ns; }
+                    if (tb < tmax) { tmax = tb; tmax_axis = xyz; tmax_s = ns; }
+                }
+                if (tmax >= tmin && tmax > 0) {
+                    c.outside = true;
+                    if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; c.outside = false; }
+                    c.axis = tmin_axis; c.sgn = tmin_s;
+                    c.objP = getPointOnRay(q, tmin);
+                    hit = true;
+                }
+            } else {                                   // sphereIntersectionTest, src/intersections.h:104-135
+                const float radius = .5f;
+                float vDotDirection = dot(q.o, q.d);
+                float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
+                if (!(radicand < 0)) {
+                    float squareRoot = __builtin_sqrtf(radicand);
+                    float firstTerm = -vDotDirection;
+                    float t1 = firstTerm + squareRoot;
+                    float t2 = firstTerm - squareRoot;
+                    if (!(t1 < 0 && t2 < 0)) {
+                        float t;
+                        if (t1 > 0 && t2 > 0) { t = fmin_glm(t1, t2); c.outside = true; }
+                        else { t = fmax_glm(t1, t2); c.outside = false; }
+                        c.objP = getPointOnRay(q, t);
+                        hit = true;
+                    }
+                }
+            }
+            if (hit) {
+                float xf[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) xf[k] = G[12 + k];
+                const vec3 point = mulRows(xf, c.objP, 1.0f);
+                const float t = length(sub(ray.o, point));
+                if (t > 0.0f && (t_min > t || (t_min == t && g < best_g))) { t_min = t; best_g = g; best = c; }
+            }
+        }
+    }
+    // meshes: uniform loop, only the lanes whose ray reaches the mesh's box take part
+    float tmp_u = 0.f, tmp_v = 0.f;
+    for (int i = 0; i < sc.ngeoms; i++) {
+        if (!__any((mesh_mask >> i) & 1u)) continue;
+        if ((mesh_mask >> i) & 1u) {
+            DGeom geom;
+            loadGeomHead(sc.geoms, i, geom);
+            Cand c;
+            c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = tmp_u; c.v = tmp_v;
+            const float t = meshTestCore(sc, geom, ray, c);
+            tmp_u = c.u; tmp_v = c.v;
+            if (t > 0.0f && (t_min > t || (t_min == t && i < best_g))) { t_min = t; best_g = i; best = c; }
+        }
+    }
+    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
+    if (best_g != -1) {
+        const float *G = gtab + best_g * GTAB_WORDS;
+        const int type = __float_as_int(G[36]);
+        h.t = t_min;
+        h.geom = best_g;
+        h.mat = __float_as_int(G[37]);
+        h.u = best.u; h.v = best.v;
+        if (type == G_OBJ) {
+            vec3 geoN;
+            h.n = meshNormal(sc, sc.geoms[best_g], best, geoN);
+        } else {
+            float invT[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
+            if (type == G_CUBE) {
+                vec3 n = V3(best.axis == 0 ? best.sgn : 0.f, best.axis == 1 ? best.sgn : 0.f, best.axis == 2 ? best.sgn : 0.f);
+                h.n = normalize(mulRows(invT, n, 0.0f));
+            } else {
+                vec3 n = normalize(mulRows(invT, best.objP, 0.f));
+                h.n = best.outside ? n : neg(n);
+            }
+        }
     }
 }
 

@@ -28,6 +28,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 
 #include "../../include/mi355x_pathtracer.h"
 #include "pt_device.h"
@@ -608,7 +609,8 @@ struct ptx_tracer {
     int32_t *d_chunk = nullptr;                          // [2][nbins][grid]
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
-    float *d_tri9 = nullptr;
+    float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
+    int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
     int kmax = 1;                                        // iterations per launch set (segments)
@@ -634,6 +636,7 @@ struct ptx_tracer {
     bool cap_filled = false;
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
+        s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -655,11 +658,44 @@ void camera_to_device(const ptx_camera &c, DCamera &d) {
     memcpy(d.up, c.up, 12); memcpy(d.right, c.right, 12); memcpy(d.fov, c.fov, 8); memcpy(d.pixelLength, c.pixelLength, 8);
 }
 
+// Conservative world-space box of a geom for the candidate pre-test of intersectSceneCull: the transformed unit cube
+// (which also contains the radius-0.5 sphere) or the transformed mesh vertices, evaluated in double and inflated by
+// 1e-3 + 1e-4 * |coordinate| -- three orders of magnitude more than the fp32 error of the exact tests or of the slab
+// pre-test itself, so a ray the exact test would report as a hit always reaches the box.  Anything non-finite gives an
+// unbounded box (never culled).
+void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6[6]) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool ok = true;
+    auto add = [&](double x, double y, double z) {
+        for (int r = 0; r < 3; r++) {
+            double v = (double)d.xf[0 * 4 + r] * x + (double)d.xf[1 * 4 + r] * y + (double)d.xf[2 * 4 + r] * z + (double)d.xf[3 * 4 + r];
+            if (!(v == v) || v > 1e30 || v < -1e30) ok = false;
+            lo[r] = std::min(lo[r], v); hi[r] = std::max(hi[r], v);
+        }
+    };
+    if (d.type == G_OBJ) {
+        if (d.faceCount == 0) ok = false;
+        for (int j = 0; j < d.faceCount; j++)
+            for (int k = 0; k < 3; k++) {
+                const float *p = &faces[((size_t)d.faceStart + j) * 15 + k * 5];
+                add(p[0], p[1], p[2]);
+            }
+    } else {
+        for (int c = 0; c < 8; c++) add((c & 1) ? 0.5 : -0.5, (c & 2) ? 0.5 : -0.5, (c & 4) ? 0.5 : -0.5);
+    }
+    for (int r = 0; r < 3; r++) {
+        if (!ok) { out6[r] = -INFINITY; out6[3 + r] = INFINITY; continue; }
+        double m = 1e-3 + 1e-4 * std::max(std::fabs(lo[r]), std::fabs(hi[r]));
+        out6[r] = nextafterf((float)(lo[r] - m), -INFINITY);
+        out6[3 + r] = nextafterf((float)(hi[r] + m), INFINITY);
+    }
+}
+
 int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
@@ -677,7 +713,7 @@ int free_tracer(ptx_tracer *t) {
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
 int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
-    const int triWords = t->tri_lds ? ((t->ntri * 24 + t->nmats * 11 + 3) & ~3) : 0;
+    const int triWords = t->tri_lds ? ((t->ntri * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb + 2 * nb + 1 + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
@@ -730,7 +766,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
             continue;
         }
         BounceParams bp;
-        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.cam = t->cam; bp.tm = t->tm;
+        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
         const bool from_cache = (b == 1 && cache_on);           // with the cache on, bounce 0 always lands in soa[2]
         bp.in = from_cache ? t->soa[2] : t->soa[0];
         bp.stage = t->soa[1];
@@ -812,7 +848,7 @@ int ptx_device_count(void) {
 void ptx_default_options(ptx_options *o) {
     memset(o, 0, sizeof *o);
     o->depth_of_field = 0; o->cache_first_bounce = 1; o->sort_by_material = 1; o->antialiasing = 1; o->bounding_box = 0;
-    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0; o->apps_variant = 0;
+    o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0; o->apps_variant = 0; o->no_cull = 0;
 }
 
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
@@ -902,7 +938,21 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
     }
     // the table goes to LDS when it leaves room for at least 2 workgroups per CU (160 KB LDS, ~19 KB of sort buffers)
-    t->tri_lds = (((size_t)t->ntri * 24 + (size_t)nmaterials * 11) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    t->tri_lds = (((size_t)t->ntri * 24 + (size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    // per-geom table for the per-lane gathers (rows 0-2 of the three matrices) and conservative world boxes
+    std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 6, 0.f);
+    for (int i = 0; i < ngeoms; i++) {
+        const DGeom &d = hg[i];
+        float *o = &hgtab[(size_t)i * 40];
+        const float *mats3[3] = {d.inv, d.xf, d.invT};
+        for (int m = 0; m < 3; m++)
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 4; c++) o[m * 12 + r * 4 + c] = mats3[m][c * 4 + r];
+        int32_t ints[4] = {d.type, d.materialid, d.faceStart, d.faceCount};
+        memcpy(o + 36, ints, sizeof ints);
+        make_world_aabb(d, hfaces, &haabb[(size_t)i * 6]);
+    }
+    t->cull = (t->tri_lds && ngeoms >= 1 && ngeoms <= 32 && !opt.no_cull) ? 1 : 0;
     if (hfaces.empty()) hfaces.resize(15, 0.f);
     if (htex.empty()) htex.resize(16, 0);
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
@@ -916,6 +966,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemcpy(t->d_faces, hfaces.data(), sizeof(float) * hfaces.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_tri9, sizeof(float) * htri9.size()));
     HC(hipMemcpy(t->d_tri9, htri9.data(), sizeof(float) * htri9.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_gtab, sizeof(float) * hgtab.size()));
+    HC(hipMemcpy(t->d_gtab, hgtab.data(), sizeof(float) * hgtab.size(), hipMemcpyHostToDevice));
+    HC(hipMalloc(&t->d_aabb, sizeof(float) * haabb.size()));
+    HC(hipMemcpy(t->d_aabb, haabb.data(), sizeof(float) * haabb.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_texels, htex.size()));
     HC(hipMemcpy(t->d_texels, htex.data(), htex.size(), hipMemcpyHostToDevice));
 

@@ -149,6 +149,8 @@ def oracle_pending_stream(O, it, bounce):
     ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),
     ("cornellSpaceship.txt", (96, 54), 8, dict(depth_of_field=1)),
     ("cornellSpaceship.txt", (96, 54), 8, dict(no_lds_triangles=1)),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(no_cull=1)),
+    ("cornellGlass.txt", (96, 54), 12, dict(no_cull=1)),
 ])
 def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
     """The permutation is the observable: after each bounce the device stream holds exactly the reference's sorted
