@@ -151,7 +151,7 @@ def main():
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
     achieved = BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "traffic_round1.json")
+    tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
             traffic = json.load(open(tj)).get(dominant)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs that a profiling gpurun call left under gpurun_out/ into the committed summaries under
+profiles/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_{fetch,write}_size.csv and
+traffic_<tag>.json (HBM bytes per launch per kernel = mean FETCH_SIZE * 1024 * 2 + mean WRITE_SIZE * 1024; FETCH_SIZE is
+in KiB and reads half of the bytes on gfx950, MI355X_MICROARCH.md "HBM").
+
+    python tools/collect_profiles.py TAG gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = {"k_bounce<false>": "k_bounce", "k_bounce<true>": "k_bounce<first>", "k_move": "k_move", "k_gather": "k_gather"}
+
+
+def main(tag, d_stats, d_fetch, d_write):
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(glob.glob(os.path.join(d_stats, "*", "*_kernel_stats.csv"))[0], os.path.join(out, "%s_kernel_stats.csv" % tag))
+    acc = {}
+    for kind, d in (("fetch", d_fetch), ("write", d_write)):
+        f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+        shutil.copy(f, os.path.join(out, "%s_pmc_%s_size.csv" % (tag, kind)))
+        a = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            for k, v in NAMES.items():
+                if k in r["Kernel_Name"]:
+                    a[v].append(float(r["Counter_Value"]))
+        acc[kind] = a
+    res, detail = {}, {}
+    for k in NAMES.values():
+        f, w = acc["fetch"].get(k), acc["write"].get(k)
+        if not f or not w:
+            continue
+        fb, wb = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
+        res[k] = fb + wb
+        detail[k] = dict(launches_sampled=len(f), fetch_size_kib_mean=sum(f) / len(f), write_size_kib_mean=sum(w) / len(w),
+                         hbm_read_bytes_per_launch=fb, hbm_write_bytes_per_launch=wb)
+    res["_detail"] = detail
+    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --steps 8 --warmup 8 "
+                   "--no-cpu-baseline; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
+                   "FETCH_SIZE correction (checked in round 1 on k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
+                   "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 8 iterations (batch 8).")
+    json.dump(res, open(os.path.join(out, "traffic_%s.json" % tag), "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
