@@ -478,10 +478,7 @@ PT_DEV void loadGeomHead(const DGeom *geoms, int i, DGeom &g) {
 
 // body of computeIntersections, src/pathtrace.cu:270-343: nearest t > 0 over all geoms, lowest index wins ties.
 // A miss leaves materialId = 0 (the reference's full-frame memset, :501), which is what the material sort sees.
-PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h);
-
 PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
-    if (sc.cull) { intersectSceneCull(sc, ray, h); return; }
     float t_min = 3.402823466e+38f;
     h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
     int hit_geom_index = -1;
@@ -523,7 +520,9 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
 // box its ray can reach (a miss of that box implies a miss of the exact test: the box is inflated far beyond fp32
 // error, see make_world_aabb in pt_engine.hip), then the wave loops "each lane takes ITS next cube or sphere" with the
 // geom tables gathered per lane from LDS.  The exact tests and their arithmetic are unchanged, so is the result:
-// nearest t > 0, lowest geom index on ties (the reference's strict `t_min > t` in index order).
+// nearest t > 0, lowest geom index on ties (the reference's strict `t_min > t` in index order).  The kernels go one
+// step further (tileIntersect in pt_engine.hip): the (ray, geom) pairs of a whole 256-path tile are pooled in LDS and
+// worked off by dense waves.
 
 // xyz of mat4*vec4 for a matrix stored as 3 rows of 4 (same products and sums as multiplyMV)
 PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
@@ -534,10 +533,9 @@ PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
     return o;
 }
 
-PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h) {
-    const float *lds_f = reinterpret_cast<const float *>(pt_lds);
-    const float *gtab = lds_f + sc.ntri * 24 + sc.nmats * 11;
-    // conservative slab test against every geom's world box (uniform index: the boxes come through the scalar path)
+// Candidate masks of one ray: bit i set <=> geom i's conservative world box is reached (uniform loop over geoms, the
+// boxes and types come through the scalar path).
+PT_DEV void cullMasks(const DScene &sc, Ray ray, uint32_t &prim_mask, uint32_t &mesh_mask) {
     typedef const __attribute__((address_space(4))) float cfloat;
     cfloat *ab = (cfloat *)sc.aabb;
     const float tiny = 1e-20f;
@@ -545,7 +543,7 @@ PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h) {
     const float ddy = __builtin_fabsf(ray.d.y) < tiny ? __builtin_copysignf(tiny, ray.d.y) : ray.d.y;
     const float ddz = __builtin_fabsf(ray.d.z) < tiny ? __builtin_copysignf(tiny, ray.d.z) : ray.d.z;
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
-    uint32_t prim_mask = 0, mesh_mask = 0;
+    prim_mask = 0; mesh_mask = 0;
     for (int i = 0; i < sc.ngeoms; i++) {
         const float x0 = (ab[i * 6 + 0] - ray.o.x) * ix, x1 = (ab[i * 6 + 3] - ray.o.x) * ix;
         const float y0 = (ab[i * 6 + 1] - ray.o.y) * iy, y1 = (ab[i * 6 + 4] - ray.o.y) * iy;
@@ -559,113 +557,160 @@ PT_DEV void intersectSceneCull(const DScene &sc, Ray ray, Hit &h) {
             else if (type == G_CUBE || type == G_SPHERE) prim_mask |= 1u << i;
         }
     }
-    float t_min = 3.402823466e+38f;
-    int best_g = -1;
-    Cand best;
-    best.axis = -1; best.sgn = 0.f; best.objP = V3(0.f, 0.f, 0.f); best.outside = true; best.face = -1; best.u = best.v = 0.f;
-    // cubes and spheres: every lane works on its own next candidate
-    while (__any(prim_mask != 0)) {
-        if (prim_mask != 0) {
-            const int g = __ffs((int)prim_mask) - 1;
-            prim_mask &= prim_mask - 1;
-            const float *G = gtab + g * GTAB_WORDS;
+}
+
+// Result of one (ray, geom) test as a 64-bit key: fp32 bits of t (t > 0, so they order like t) << 32 | geom << 24 |
+// 24 bits that let the winner rebuild its normal (cube: axis+1, sign, outside; mesh: face).  The minimum key over a
+// ray's candidates is the reference's answer: nearest t, lowest geom index on ties.
+constexpr unsigned long long KEY_NONE = ~0ull;
+PT_DEV unsigned long long packKey(float t, int g, uint32_t aux) {
+    return ((unsigned long long)(uint32_t)__float_as_int(t) << 32) | ((unsigned long long)(uint32_t)g << 24) | (aux & 0xffffffu);
+}
+
+// cube or sphere g (per-lane g: tables gathered from LDS) against one ray.  Accepts what the reference's
+// `t > 0.0f && t_min > t` can accept (t_min starts at FLT_MAX).
+PT_DEV unsigned long long primKey(const float *gtab, int g, Ray ray) {
+    const float *G = gtab + g * GTAB_WORDS;
+    float inv[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) inv[k] = G[k];
+    const int type = __float_as_int(G[36]);
+    Ray q;
+    q.o = mulRows(inv, ray.o, 1.0f);
+    q.d = normalize(mulRows(inv, ray.d, 0.0f));
+    vec3 objP = V3(0.f, 0.f, 0.f);
+    uint32_t aux = 0;
+    bool hit = false;
+    if (type == G_CUBE) {                      // boxIntersectionTest, src/intersections.h:54-84
+        float tmin = -1e38f, tmax = 1e38f;
+        int tmin_axis = -1, tmax_axis = -1;
+        float tmin_s = 0.f, tmax_s = 0.f;
+        const float qo[3] = {q.o.x, q.o.y, q.o.z};
+        const float qd[3] = {q.d.x, q.d.y, q.d.z};
+#pragma unroll
+        for (int xyz = 0; xyz < 3; ++xyz) {
+            float t1 = (-0.5f - qo[xyz]) / qd[xyz];
+            float t2 = (+0.5f - qo[xyz]) / qd[xyz];
+            float ta = fmin_glm(t1, t2);
+            float tb = fmax_glm(t1, t2);
+            float ns = t2 < t1 ? +1.f : -1.f;
+            if (ta > 0 && ta > tmin) { tmin = ta; tmin_axis = xyz; tmin_s = ns; }
+            if (tb < tmax) { tmax = tb; tmax_axis = xyz; tmax_s = ns; }
+        }
+        if (tmax >= tmin && tmax > 0) {
+            bool outside = true;
+            if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; outside = false; }
+            aux = (uint32_t)(tmin_axis + 1) | (tmin_s > 0.f ? 4u : 0u) | (outside ? 8u : 0u);
+            objP = getPointOnRay(q, tmin);
+            hit = true;
+        }
+    } else {                                   // sphereIntersectionTest, src/intersections.h:104-135
+        const float radius = .5f;
+        float vDotDirection = dot(q.o, q.d);
+        float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
+        if (!(radicand < 0)) {
+            float squareRoot = __builtin_sqrtf(radicand);
+            float firstTerm = -vDotDirection;
+            float t1 = firstTerm + squareRoot;
+            float t2 = firstTerm - squareRoot;
+            if (!(t1 < 0 && t2 < 0)) {
+                float t;
+                bool outside;
+                if (t1 > 0 && t2 > 0) { t = fmin_glm(t1, t2); outside = true; }
+                else { t = fmax_glm(t1, t2); outside = false; }
+                aux = outside ? 8u : 0u;
+                objP = getPointOnRay(q, t);
+                hit = true;
+            }
+        }
+    }
+    if (!hit) return KEY_NONE;
+    float xf[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) xf[k] = G[12 + k];
+    const vec3 point = mulRows(xf, objP, 1.0f);
+    const float t = length(sub(ray.o, point));
+    if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
+    return packKey(t, g, aux);
+}
+
+// mesh g against one ray (g may differ per lane: its header is gathered from LDS)
+PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ray ray) {
+    const float *G = gtab + g * GTAB_WORDS;
+    DGeom geom;
+    // rows -> glm column-major for the shared mesh routine: only inv is read there
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) geom.inv[c * 4 + r] = G[r * 4 + c];
+    geom.type = G_OBJ;
+    geom.faceStart = __float_as_int(G[38]); geom.faceCount = __float_as_int(G[39]);
+    Cand c;
+    c.face = -1; c.u = 0.f; c.v = 0.f;
+    const float t = meshTestCore(sc, geom, ray, c);
+    if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
+    return packKey(t, g, (uint32_t)c.face);
+}
+
+// What the winning key stands for: t, geom, material, normal (and texcoords when the scene uses them).
+PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long key, Ray ray, bool need_uv, Hit &h) {
+    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
+    if (key == KEY_NONE) return;
+    const int g = (int)((key >> 24) & 0xff);
+    const uint32_t aux = (uint32_t)(key & 0xffffffu);
+    const float *G = gtab + g * GTAB_WORDS;
+    const int type = __float_as_int(G[36]);
+    h.t = __int_as_float((int)(uint32_t)(key >> 32));
+    h.geom = g;
+    h.mat = __float_as_int(G[37]);
+    if (type == G_OBJ) {
+        Cand c;
+        c.face = (int)aux; c.u = 0.f; c.v = 0.f;
+        const DGeom &geom = sc.geoms[g];
+        if (need_uv) {      // texcoords of the winning face: redo its barycentrics (same arithmetic, same bits)
+            Ray q;
+            q.o = multiplyMV(geom.inv, ray.o, 1.0f);
+            q.d = normalize(multiplyMV(geom.inv, ray.d, 0.0f));
+            const int f = geom.faceStart + c.face;
+            vec3 v0 = faceVec(sc, f, 0);
+            vec3 e1 = sub(faceVec(sc, f, 5), v0), e2 = sub(faceVec(sc, f, 10), v0);
+            float b0 = 0.f, b1 = 0.f;
+            rayTriangle(q.o, q.d, v0, e1, e2, b0, b1);
+            float w = 1 - b0 - b1;
+            c.u = (w * faceWord(sc, f, 3) + b0 * faceWord(sc, f, 8)) + b1 * faceWord(sc, f, 13);
+            c.v = (w * faceWord(sc, f, 4) + b0 * faceWord(sc, f, 9)) + b1 * faceWord(sc, f, 14);
+        }
+        h.u = c.u; h.v = c.v;
+        vec3 geoN;
+        h.n = meshNormal(sc, geom, c, geoN);
+    } else {
+        float invT[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
+        if (type == G_CUBE) {
+            const int axis = (int)(aux & 3u) - 1;
+            const float sgn = (aux & 4u) ? 1.f : -1.f;
+            vec3 n = V3(axis == 0 ? sgn : 0.f, axis == 1 ? sgn : 0.f, axis == 2 ? sgn : 0.f);
+            h.n = normalize(mulRows(invT, n, 0.0f));
+        } else {            // sphere: the object-space hit point is recomputed (same arithmetic as in primKey)
             float inv[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) inv[k] = G[k];
-            const int type = __float_as_int(G[36]);
             Ray q;
             q.o = mulRows(inv, ray.o, 1.0f);
             q.d = normalize(mulRows(inv, ray.d, 0.0f));
-            Cand c;
-            c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = c.v = 0.f;
-            bool hit = false;
-            if (type == G_CUBE) {                      // boxIntersectionTest, src/intersections.h:54-84
-                float tmin = -1e38f, tmax = 1e38f;
-                int tmin_axis = -1, tmax_axis = -1;
-                float tmin_s = 0.f, tmax_s = 0.f;
-                const float qo[3] = {q.o.x, q.o.y, q.o.z};
-                const float qd[3] = {q.d.x, q.d.y, q.d.z};
-#pragma unroll
-                for (int xyz = 0; xyz < 3; ++xyz) {
-                    float t1 = (-0.5f - qo[xyz]) / qd[xyz];
-                    float t2 = (+0.5f - qo[xyz]) / qd[xyz];
-                    float ta = fmin_glm(t1, t2);
-                    float tb = fmax_glm(t1, t2);
-                    float ns = t2 < t1 ? +1.f : -1.f;
-                    if (ta > 0 && ta > tmin) { tmin = ta; tmin_axis = xyz; tmin_s = ns; }
-                    if (tb < tmax) { tmax = tb; tmax_axis = xyz; tmax_s = ns; }
-                }
-                if (tmax >= tmin && tmax > 0) {
-                    c.outside = true;
-                    if (tmin <= 0) { tmin = tmax; tmin_axis = tmax_axis; tmin_s = tmax_s; c.outside = false; }
-                    c.axis = tmin_axis; c.sgn = tmin_s;
-                    c.objP = getPointOnRay(q, tmin);
-                    hit = true;
-                }
-            } else {                                   // sphereIntersectionTest, src/intersections.h:104-135
-                const float radius = .5f;
-                float vDotDirection = dot(q.o, q.d);
-                float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
-                if (!(radicand < 0)) {
-                    float squareRoot = __builtin_sqrtf(radicand);
-                    float firstTerm = -vDotDirection;
-                    float t1 = firstTerm + squareRoot;
-                    float t2 = firstTerm - squareRoot;
-                    if (!(t1 < 0 && t2 < 0)) {
-                        float t;
-                        if (t1 > 0 && t2 > 0) { t = fmin_glm(t1, t2); c.outside = true; }
-                        else { t = fmax_glm(t1, t2); c.outside = false; }
-                        c.objP = getPointOnRay(q, t);
-                        hit = true;
-                    }
-                }
-            }
-            if (hit) {
-                float xf[12];
-#pragma unroll
-                for (int k = 0; k < 12; k++) xf[k] = G[12 + k];
-                const vec3 point = mulRows(xf, c.objP, 1.0f);
-                const float t = length(sub(ray.o, point));
-                if (t > 0.0f && (t_min > t || (t_min == t && g < best_g))) { t_min = t; best_g = g; best = c; }
-            }
-        }
-    }
-    // meshes: uniform loop, only the lanes whose ray reaches the mesh's box take part
-    float tmp_u = 0.f, tmp_v = 0.f;
-    for (int i = 0; i < sc.ngeoms; i++) {
-        if (!__any((mesh_mask >> i) & 1u)) continue;
-        if ((mesh_mask >> i) & 1u) {
-            DGeom geom;
-            loadGeomHead(sc.geoms, i, geom);
-            Cand c;
-            c.axis = -1; c.sgn = 0.f; c.objP = V3(0.f, 0.f, 0.f); c.outside = true; c.face = -1; c.u = tmp_u; c.v = tmp_v;
-            const float t = meshTestCore(sc, geom, ray, c);
-            tmp_u = c.u; tmp_v = c.v;
-            if (t > 0.0f && (t_min > t || (t_min == t && i < best_g))) { t_min = t; best_g = i; best = c; }
-        }
-    }
-    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
-    if (best_g != -1) {
-        const float *G = gtab + best_g * GTAB_WORDS;
-        const int type = __float_as_int(G[36]);
-        h.t = t_min;
-        h.geom = best_g;
-        h.mat = __float_as_int(G[37]);
-        h.u = best.u; h.v = best.v;
-        if (type == G_OBJ) {
-            vec3 geoN;
-            h.n = meshNormal(sc, sc.geoms[best_g], best, geoN);
-        } else {
-            float invT[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
-            if (type == G_CUBE) {
-                vec3 n = V3(best.axis == 0 ? best.sgn : 0.f, best.axis == 1 ? best.sgn : 0.f, best.axis == 2 ? best.sgn : 0.f);
-                h.n = normalize(mulRows(invT, n, 0.0f));
-            } else {
-                vec3 n = normalize(mulRows(invT, best.objP, 0.f));
-                h.n = best.outside ? n : neg(n);
-            }
+            const float radius = .5f;
+            float vDotDirection = dot(q.o, q.d);
+            float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
+            float squareRoot = __builtin_sqrtf(radicand);
+            float firstTerm = -vDotDirection;
+            float t1 = firstTerm + squareRoot;
+            float t2 = firstTerm - squareRoot;
+            const bool outside = (aux & 8u) != 0;
+            float t = outside ? fmin_glm(t1, t2) : fmax_glm(t1, t2);
+            vec3 objP = getPointOnRay(q, t);
+            vec3 n = normalize(mulRows(invT, objP, 0.f));
+            h.n = outside ? n : neg(n);
         }
     }
 }

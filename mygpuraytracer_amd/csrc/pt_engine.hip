@@ -52,6 +52,8 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #endif
 constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
+// words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets
+constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1) + 3) & ~3; }
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
@@ -160,6 +162,68 @@ __device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, f
     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z;
 }
 
+// computeIntersections for a whole tile, cooperatively.  Every ray lists the geoms whose conservative world box it
+// reaches (cullMasks); the (ray, geom) pairs of the tile are pooled in LDS -- cubes and spheres first, meshes after --
+// and worked off by dense waves, each pair folding its result into its ray's 64-bit minimum with an LDS atomic
+// (primKey / meshKey / packKey: min key = nearest t, lowest geom index on ties, i.e. the reference's answer).  In a
+// wave of incoherent rays this replaces "every lane waits for all 7 geoms" by "about 1.3 pairs per ray, packed".
+// Must be called by all threads of the workgroup (barriers inside); `scratch` = TILE*17 words of LDS.
+constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contribute per pass (1024-entry list)
+__device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
+                                              int tid, int lane, int wave) {
+    const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + sc.nmats * 11;
+    float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
+    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [ITEMS_PER_PASS*TILE]: ray | geom << 8
+    int32_t *wtot = scratch + 8 * TILE + ITEMS_PER_PASS * TILE / 2;                // [2][WAVES] wave totals
+    uint32_t prim_mask = 0, mesh_mask = 0;
+    if (alive) cullMasks(sc, ray, prim_mask, mesh_mask);
+    rayb[0 * TILE + tid] = ray.o.x; rayb[1 * TILE + tid] = ray.o.y; rayb[2 * TILE + tid] = ray.o.z;
+    rayb[3 * TILE + tid] = ray.d.x; rayb[4 * TILE + tid] = ray.d.y; rayb[5 * TILE + tid] = ray.d.z;
+    best[tid] = KEY_NONE;
+    for (;;) {
+        // this pass: up to ITEMS_PER_PASS pairs per ray, cubes/spheres before meshes
+        const int np = min(__popc(prim_mask), ITEMS_PER_PASS);
+        const int nm = min(__popc(mesh_mask), ITEMS_PER_PASS - np);
+        int ip = np, im = nm;                          // inclusive wave scans
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int a = __shfl_up(ip, off), b = __shfl_up(im, off);
+            if (lane >= off) { ip += a; im += b; }
+        }
+        if (lane == 63) { wtot[wave] = ip; wtot[WAVES + wave] = im; }
+        __syncthreads();
+        int totP = 0, totM = 0, offP = ip - np, offM = im - nm;
+        for (int w = 0; w < WAVES; w++) {
+            if (w < wave) { offP += wtot[w]; offM += wtot[WAVES + w]; }
+            totP += wtot[w]; totM += wtot[WAVES + w];
+        }
+        for (int j = 0; j < np; j++) {
+            const int g = __ffs((int)prim_mask) - 1;
+            prim_mask &= prim_mask - 1;
+            list[offP + j] = (uint16_t)(tid | (g << 8));
+        }
+        for (int j = 0; j < nm; j++) {
+            const int g = __ffs((int)mesh_mask) - 1;
+            mesh_mask &= mesh_mask - 1;
+            list[totP + offM + j] = (uint16_t)(tid | (g << 8));
+        }
+        __syncthreads();
+        for (int k = tid; k < totP + totM; k += TILE) {
+            const int item = list[k], src = item & 0xff, g = item >> 8;
+            Ray r;
+            r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
+            r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
+            const unsigned long long key = k < totP ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r);
+            if (key != KEY_NONE) atomicMin(&best[src], key);
+        }
+        // another pass only if some ray still has candidates (rare: more than ITEMS_PER_PASS boxes along one ray)
+        if (!__syncthreads_or((prim_mask | mesh_mask) != 0)) break;
+    }
+    decodeKey(sc, gtab, best[tid], ray, need_uv, hit);
+    __syncthreads();                                   // scratch is reused by the caller
+}
+
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 template <bool FIRST>
 __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
@@ -172,7 +236,8 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
-    int32_t *rec = toff + nb + 1;                                   // [17][TILE] record transpose buffer
+    int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
+                                                                    // 16-byte aligned (64-bit LDS atomics live in it)
     if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
     __syncthreads();
@@ -228,9 +293,12 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         bool pending = false;
         Hit hit;
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
-        if (alive) {
+        {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
-            intersectScene(p.sc, ray, hit);
+            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tid, lane, wave);
+            else if (alive) intersectScene(p.sc, ray, hit);
+        }
+        if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
             if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
             bool lit = false;
@@ -714,7 +782,7 @@ int free_tracer(ptx_tracer *t) {
 int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
     const int triWords = t->tri_lds ? ((t->ntri * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
-    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + 2 * WAVES * nb + 2 * nb + 2 * nb + 1 + 17 * TILE);
+    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
