@@ -180,6 +180,8 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
+/* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
+int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]);
 /* fields14 (optional): 14 rows of min(n, cap) floats: px py pz (= origin + t*direction, the point that will be
  * shaded) dx dy dz cr cg cb nx ny nz u v (u, v only meaningful when the scene has textures) */
 int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx,

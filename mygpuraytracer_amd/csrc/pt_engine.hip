@@ -110,6 +110,7 @@ struct BounceParams {
     // batching: blockIdx.y = segment = one iteration of the batch (iteration p.iter + segment), each an independent
     // stream with its own buffers at these strides (in elements)
     size_t seg_in, seg_stage, seg_counts, seg_chunk, seg_totals, seg_part;
+    unsigned long long *stamps;            // diagnostic build (-DPT_STAMPS) only: cycles per phase, summed over waves
     float *part;                           // != NULL: every ending path STORES its radiance to part[segment][pix]
                                            // (k_gather adds the segments to the image in iteration order)
     // first-bounce cache fill (iter 1, AA and DoF off): bounce-0 light hits are replayed on later iterations
@@ -169,8 +170,17 @@ __device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, f
 // wave of incoherent rays this replaces "every lane waits for all 7 geoms" by "about 1.3 pairs per ray, packed".
 // Must be called by all threads of the workgroup (barriers inside); `scratch` = TILE*17 words of LDS.
 constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contribute per pass (1024-entry list)
+#ifdef PT_STAMPS
+#define TI_STAMP(k) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t1_ - st_t0; st_t0 = t1_; } while (0)
+#define TI_ARGS , unsigned long long *st_acc, unsigned long long &st_t0
+#define TI_PASS , st_acc, st_t0
+#else
+#define TI_STAMP(k) do { } while (0)
+#define TI_ARGS
+#define TI_PASS
+#endif
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
-                                              int tid, int lane, int wave) {
+                                              int tid, int lane, int wave TI_ARGS) {
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
@@ -209,6 +219,10 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
             list[totP + offM + j] = (uint16_t)(tid | (g << 8));
         }
         __syncthreads();
+        TI_STAMP(5);
+#ifdef PT_STAMPS
+        if (tid == 0) { st_acc[8] += totP; st_acc[9] += totM; st_acc[10] += 1; }
+#endif
         for (int k = tid; k < totP + totM; k += TILE) {
             const int item = list[k], src = item & 0xff, g = item >> 8;
             Ray r;
@@ -218,10 +232,13 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
             if (key != KEY_NONE) atomicMin(&best[src], key);
         }
         // another pass only if some ray still has candidates (rare: more than ITEMS_PER_PASS boxes along one ray)
-        if (!__syncthreads_or((prim_mask | mesh_mask) != 0)) break;
+        const int more = __syncthreads_or((prim_mask | mesh_mask) != 0);
+        TI_STAMP(6);
+        if (!more) break;
     }
     decodeKey(sc, gtab, best[tid], ray, need_uv, hit);
     __syncthreads();                                   // scratch is reused by the caller
+    TI_STAMP(7);
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
@@ -255,7 +272,16 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     // (running sum inside the chunk) and no separate scan pass over the tiles is needed
     const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
+#ifdef PT_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
+#define STAMP(k) do { st_t1 = __builtin_amdgcn_s_memtime(); st_acc[k] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
     for (int tile = tile0; tile < tile1; tile++) {
+#ifdef PT_STAMPS
+        st_t0 = __builtin_amdgcn_s_memtime();
+#endif
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
         PathState ps;
@@ -288,6 +314,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
                 }
             }
         }
+        STAMP(0);        // load + shade (or ray generation)
         // computeIntersections(b) + the terminal cases of shadeFakeMaterial(b)
         int bin = -1;
         bool pending = false;
@@ -295,9 +322,10 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
         {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
-            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tid, lane, wave);
+            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tid, lane, wave TI_PASS);
             else if (alive) intersectScene(p.sc, ray, hit);
         }
+        STAMP(1);        // intersect
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
             if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
@@ -325,6 +353,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
                 px[0] = 0.f; px[1] = 0.f; px[2] = 0.f;
             }
         }
+        STAMP(2);        // classify + deposit
         // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
         // index) and among the stored ones (-> storage position)
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
@@ -369,6 +398,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
             toff[nb] = o;
         }
         __syncthreads();
+        STAMP(3);        // ranking + counts
         // Stored paths go to the stage sorted by bin inside the tile (through LDS), so that both this write and
         // k_move's read are dense and coalesced and k_move's scattered write falls into per-bin runs.
         if (pending) {
@@ -403,7 +433,12 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
             }
         }
         __syncthreads();
+        STAMP(4);        // sort through LDS + stage write
     }
+#ifdef PT_STAMPS
+    if (lane == 0 && p.stamps)
+        for (int k = 0; k < 11; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
+#endif
     for (int b = tid; b < nb; b += TILE) {
         const int ca = run_all[b], cs = run_scat[b];
         chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
@@ -684,6 +719,7 @@ struct ptx_tracer {
     int kmax = 1;                                        // iterations per launch set (segments)
     int uses_uv = 0;
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
+    unsigned long long *d_stamps = nullptr;              // diagnostic build only
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
@@ -767,7 +803,7 @@ int free_tracer(ptx_tracer *t) {
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
-    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
@@ -850,6 +886,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
         bp.nsuper = t->nsuper;
         bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = (size_t)t->cap;
         bp.seg_counts = seg_counts; bp.seg_chunk = seg_chunk; bp.seg_totals = seg_totals;
+        bp.stamps = t->d_stamps;
         bp.part = batched ? t->d_part : nullptr; bp.seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
@@ -1081,6 +1118,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemset(t->d_emit_count, 0, sizeof(int32_t)));
     HC(hipMalloc(&t->d_emit_pix, sizeof(int32_t) * (size_t)t->cap));
     HC(hipMalloc(&t->d_emit_rgb, sizeof(float) * 3 * (size_t)t->cap));
+#ifdef PT_STAMPS
+    HC(hipMalloc(&t->d_stamps, sizeof(unsigned long long) * 32));
+    HC(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * 32));
+#endif
     HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 65));
     HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 65));
 #undef HC
@@ -1347,6 +1388,18 @@ int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_b
         ms_by_kind[kind] += ms; launches_by_kind[kind]++;
     }
     t->kev_used = 0;
+    return PTX_OK;
+}
+
+// diagnostic build (-DPT_STAMPS): cycles per phase of k_bounce summed over waves: [0..4] first bounce, [8..12] later bounces
+int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]) {
+    if (!t || !out32) return set_error(PTX_ERR_INVALID, "null argument");
+    memset(out32, 0, sizeof(unsigned long long) * 32);
+    if (!t->d_stamps) return PTX_OK;
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(out32, t->d_stamps, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * 32));
     return PTX_OK;
 }
 
