@@ -211,7 +211,8 @@ struct DScene {
     int32_t ntri;
     const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
                                         // invTranspose rows 0-2 (12), type, materialid, faceStart, faceCount
-    const float *__restrict__ aabb;     // 6 floats per geom: conservative world-space box (min xyz, max xyz), or NULL
+    const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box (min xyz, pad, max xyz, pad), or NULL
+    uint32_t prim_bits, mesh_bits;      // bit i: geom i is a cube or sphere / a mesh (geoms of unknown type are in neither)
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
@@ -533,9 +534,10 @@ PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
     return o;
 }
 
-// Candidate masks of one ray: bit i set <=> geom i's conservative world box is reached (uniform loop over geoms, the
-// boxes and types come through the scalar path).
-PT_DEV void cullMasks(const DScene &sc, Ray ray, uint32_t &prim_mask, uint32_t &mesh_mask) {
+// Candidate mask of one ray: bit i set <=> geom i's conservative world box is reached (uniform loop over geoms, two
+// boxes per trip so their scalar loads overlap; 8 floats per box: min xyz, pad, max xyz, pad).  Which of the set bits
+// are cubes/spheres and which are meshes is a per-scene constant (sc.prim_bits / sc.mesh_bits).
+PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
     typedef const __attribute__((address_space(4))) float cfloat;
     cfloat *ab = (cfloat *)sc.aabb;
     const float tiny = 1e-20f;
@@ -543,20 +545,25 @@ PT_DEV void cullMasks(const DScene &sc, Ray ray, uint32_t &prim_mask, uint32_t &
     const float ddy = __builtin_fabsf(ray.d.y) < tiny ? __builtin_copysignf(tiny, ray.d.y) : ray.d.y;
     const float ddz = __builtin_fabsf(ray.d.z) < tiny ? __builtin_copysignf(tiny, ray.d.z) : ray.d.z;
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
-    prim_mask = 0; mesh_mask = 0;
-    for (int i = 0; i < sc.ngeoms; i++) {
-        const float x0 = (ab[i * 6 + 0] - ray.o.x) * ix, x1 = (ab[i * 6 + 3] - ray.o.x) * ix;
-        const float y0 = (ab[i * 6 + 1] - ray.o.y) * iy, y1 = (ab[i * 6 + 4] - ray.o.y) * iy;
-        const float z0 = (ab[i * 6 + 2] - ray.o.z) * iz, z1 = (ab[i * 6 + 5] - ray.o.z) * iz;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-        const bool culled = (tf < tn) || (tf < 0.0f);          // any NaN => not culled
-        const int type = __float_as_int(((cfloat *)sc.gtab)[i * GTAB_WORDS + 36]);
-        if (!culled) {
-            if (type == G_OBJ) mesh_mask |= 1u << i;
-            else if (type == G_CUBE || type == G_SPHERE) prim_mask |= 1u << i;
+    uint32_t mask = 0;
+    const int n = sc.ngeoms;
+    for (int i = 0; i < n; i += 2) {
+        const int j = i + 1 < n ? i + 1 : i;
+        float bx[2][8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[j * 8 + k]; }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float x0 = (bx[h][0] - ray.o.x) * ix, x1 = (bx[h][4] - ray.o.x) * ix;
+            const float y0 = (bx[h][1] - ray.o.y) * iy, y1 = (bx[h][5] - ray.o.y) * iy;
+            const float z0 = (bx[h][2] - ray.o.z) * iz, z1 = (bx[h][6] - ray.o.z) * iz;
+            const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+            const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+            const bool culled = (tf < tn) || (tf < 0.0f);      // any NaN => not culled
+            mask |= culled ? 0u : (1u << (h ? j : i));
         }
     }
+    return mask;
 }
 
 // Result of one (ray, geom) test as a 64-bit key: fp32 bits of t (t > 0, so they order like t) << 32 | geom << 24 |

@@ -52,8 +52,9 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #endif
 constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
-// words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets
-constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1) + 3) & ~3; }
+// words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
+// tileIntersect's 2 x 3 list counters
+constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 6) + 3) & ~3; }
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
@@ -163,8 +164,13 @@ __device__ __forceinline__ void write_albedo(const DScene &sc, const Hit &hit, f
     dst[0] = a.x; dst[1] = a.y; dst[2] = a.z;
 }
 
+// number of set bits of a wave ballot below this lane
+__device__ __forceinline__ int wavePrefix(unsigned long long b, int lane) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+
 // computeIntersections for a whole tile, cooperatively.  Every ray lists the geoms whose conservative world box it
-// reaches (cullMasks); the (ray, geom) pairs of the tile are pooled in LDS -- cubes and spheres first, meshes after --
+// reaches (cullMask); the (ray, geom) pairs of the tile are pooled in LDS -- cubes and spheres first, meshes after --
 // and worked off by dense waves, each pair folding its result into its ray's 64-bit minimum with an LDS atomic
 // (primKey / meshKey / packKey: min key = nearest t, lowest geom index on ties, i.e. the reference's answer).  In a
 // wave of incoherent rays this replaces "every lane waits for all 7 geoms" by "about 1.3 pairs per ray, packed".
@@ -180,64 +186,72 @@ constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contri
 #define TI_PASS
 #endif
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
-                                              int tid, int lane, int wave TI_ARGS) {
+                                              int32_t *tcnt, int &q, int tid, int lane, int wave TI_ARGS) {
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
-    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [ITEMS_PER_PASS*TILE]: ray | geom << 8
-    int32_t *wtot = scratch + 8 * TILE + ITEMS_PER_PASS * TILE / 2;                // [2][WAVES] wave totals
+    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [ITEMS_PER_PASS*TILE]: ray | geom << 8,
+    constexpr int CAP = ITEMS_PER_PASS * TILE;                                     // cubes/spheres from the front, meshes from the back
     uint32_t prim_mask = 0, mesh_mask = 0;
-    if (alive) cullMasks(sc, ray, prim_mask, mesh_mask);
+    if (alive) { const uint32_t m = cullMask(sc, ray); prim_mask = m & sc.prim_bits; mesh_mask = m & sc.mesh_bits; }
     rayb[0 * TILE + tid] = ray.o.x; rayb[1 * TILE + tid] = ray.o.y; rayb[2 * TILE + tid] = ray.o.z;
     rayb[3 * TILE + tid] = ray.d.x; rayb[4 * TILE + tid] = ray.d.y; rayb[5 * TILE + tid] = ray.d.z;
     best[tid] = KEY_NONE;
     for (;;) {
-        // this pass: up to ITEMS_PER_PASS pairs per ray, cubes/spheres before meshes
-        const int np = min(__popc(prim_mask), ITEMS_PER_PASS);
-        const int nm = min(__popc(mesh_mask), ITEMS_PER_PASS - np);
-        int ip = np, im = nm;                          // inclusive wave scans
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int a = __shfl_up(ip, off), b = __shfl_up(im, off);
-            if (lane >= off) { ip += a; im += b; }
+        // this pass: up to ITEMS_PER_PASS pairs per ray, cubes/spheres before meshes.  Slots: prefix inside the wave
+        // from ballots of the 3-bit counts, one LDS atomic per wave for its base (tcnt[3q..]: pairs of cubes/spheres,
+        // pairs of meshes, "some ray has more"; the other parity's counters are cleared meanwhile for the next pass).
+        const int cp = (int)__popc(prim_mask), cm = (int)__popc(mesh_mask);
+        const int np = cp < ITEMS_PER_PASS ? cp : ITEMS_PER_PASS;
+        const int nm = cm < ITEMS_PER_PASS - np ? cm : ITEMS_PER_PASS - np;
+        const unsigned long long p0 = __ballot(np & 1), p1 = __ballot(np & 2), p2 = __ballot(np & 4);
+        const unsigned long long m0 = __ballot(nm & 1), m1 = __ballot(nm & 2), m2 = __ballot(nm & 4);
+        const unsigned long long left = __ballot(cp + cm > np + nm);
+        const int exP = wavePrefix(p0, lane) + 2 * wavePrefix(p1, lane) + 4 * wavePrefix(p2, lane);
+        const int exM = wavePrefix(m0, lane) + 2 * wavePrefix(m1, lane) + 4 * wavePrefix(m2, lane);
+        const int wP = __popcll(p0) + 2 * __popcll(p1) + 4 * __popcll(p2);
+        const int wM = __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
+        int baseP = 0, baseM = 0;
+        if (lane == 0) {
+            if (wP) baseP = atomicAdd(&tcnt[3 * q + 0], wP);
+            if (wM) baseM = atomicAdd(&tcnt[3 * q + 1], wM);
+            if (left) tcnt[3 * q + 2] = 1;
         }
-        if (lane == 63) { wtot[wave] = ip; wtot[WAVES + wave] = im; }
-        __syncthreads();
-        int totP = 0, totM = 0, offP = ip - np, offM = im - nm;
-        for (int w = 0; w < WAVES; w++) {
-            if (w < wave) { offP += wtot[w]; offM += wtot[WAVES + w]; }
-            totP += wtot[w]; totM += wtot[WAVES + w];
-        }
+        baseP = __builtin_amdgcn_readfirstlane(baseP) + exP;
+        baseM = __builtin_amdgcn_readfirstlane(baseM) + exM;
         for (int j = 0; j < np; j++) {
             const int g = __ffs((int)prim_mask) - 1;
             prim_mask &= prim_mask - 1;
-            list[offP + j] = (uint16_t)(tid | (g << 8));
+            list[baseP + j] = (uint16_t)(tid | (g << 8));
         }
         for (int j = 0; j < nm; j++) {
             const int g = __ffs((int)mesh_mask) - 1;
             mesh_mask &= mesh_mask - 1;
-            list[totP + offM + j] = (uint16_t)(tid | (g << 8));
+            list[CAP - 1 - (baseM + j)] = (uint16_t)(tid | (g << 8));
         }
         __syncthreads();
+        const int totP = tcnt[3 * q + 0], totM = tcnt[3 * q + 1], more = tcnt[3 * q + 2];
+        if (tid == 0) { tcnt[3 * (q ^ 1) + 0] = 0; tcnt[3 * (q ^ 1) + 1] = 0; tcnt[3 * (q ^ 1) + 2] = 0; }
         TI_STAMP(5);
 #ifdef PT_STAMPS
         if (tid == 0) { st_acc[8] += totP; st_acc[9] += totM; st_acc[10] += 1; }
 #endif
         for (int k = tid; k < totP + totM; k += TILE) {
-            const int item = list[k], src = item & 0xff, g = item >> 8;
+            const int item = k < totP ? list[k] : list[CAP - 1 - (k - totP)], src = item & 0xff, g = item >> 8;
             Ray r;
             r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
             r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
             const unsigned long long key = k < totP ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r);
             if (key != KEY_NONE) atomicMin(&best[src], key);
         }
-        // another pass only if some ray still has candidates (rare: more than ITEMS_PER_PASS boxes along one ray)
-        const int more = __syncthreads_or((prim_mask | mesh_mask) != 0);
+        __syncthreads();
+        q ^= 1;
         TI_STAMP(6);
+        // another pass only if some ray still has candidates (rare: more than ITEMS_PER_PASS boxes along one ray)
         if (!more) break;
     }
+    // no barrier here: the caller passes at least two before it touches `scratch` again
     decodeKey(sc, gtab, best[tid], ray, need_uv, hit);
-    __syncthreads();                                   // scratch is reused by the caller
     TI_STAMP(7);
 }
 
@@ -253,10 +267,13 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
+    int32_t *tcnt = toff + nb + 1;                                  // tileIntersect's list counters [2][3], zero between uses
+    int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
     if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
+    if (tid < 6) tcnt[tid] = 0;
     __syncthreads();
     const int seg = blockIdx.y;
     const int iter = p.iter + seg;
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         bool alive = i < n_in;
         PathState ps;
         int pix = 0;
+        for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         if (alive) {
             if (FIRST) {
@@ -322,8 +340,11 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
         {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
-            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tid, lane, wave TI_PASS);
-            else if (alive) intersectScene(p.sc, ray, hit);
+            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave TI_PASS);
+            else {
+                if (alive) intersectScene(p.sc, ray, hit);
+                __syncthreads();                                  // histogram zeroed (tileIntersect has barriers of its own)
+            }
         }
         STAMP(1);        // intersect
         if (alive) {
@@ -356,8 +377,6 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         STAMP(2);        // classify + deposit
         // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
         // index) and among the stored ones (-> storage position)
-        for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
-        __syncthreads();
         int r_all = 0, r_scat = 0;
         {
             unsigned long long remaining = __ballot(alive);
@@ -382,22 +401,45 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
         if (alive) {
             for (int w = 0; w < wave; w++) { r_all += w_all[w * nb + bin]; r_scat += w_scat[w * nb + bin]; }
         }
-        for (int b = tid; b < nb; b += TILE) {
-            int ca = 0, cs = 0;
-            for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
-            counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
-            counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
-            run_all[b] += ca;
-            run_scat[b] += cs;
-            tcs[b] = cs;
+        if (nb <= 64) {
+            // wave 0: lane b owns bin b -- tile counts, running prefixes and the in-tile offsets by a wave scan
+            if (wave == 0) {
+                int ca = 0, cs = 0;
+                if (lane < nb) {
+                    for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + lane]; cs += w_scat[w * nb + lane]; }
+                    counts_all[(size_t)lane * p.maxTiles + tile] = run_all[lane];
+                    counts_scat[(size_t)lane * p.maxTiles + tile] = run_scat[lane];
+                    run_all[lane] += ca;
+                    run_scat[lane] += cs;
+                }
+                int inc = cs;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int a = __shfl_up(inc, off);
+                    if (lane >= off) inc += a;
+                }
+                if (lane < nb) toff[lane] = inc - cs;
+                if (lane == nb - 1) toff[nb] = inc;
+            }
+            __syncthreads();
+        } else {
+            for (int b = tid; b < nb; b += TILE) {
+                int ca = 0, cs = 0;
+                for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
+                counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
+                counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+                run_all[b] += ca;
+                run_scat[b] += cs;
+                tcs[b] = cs;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int o = 0;
+                for (int b = 0; b < nb; b++) { toff[b] = o; o += tcs[b]; }
+                toff[nb] = o;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) {
-            int o = 0;
-            for (int b = 0; b < nb; b++) { toff[b] = o; o += tcs[b]; }
-            toff[nb] = o;
-        }
-        __syncthreads();
         STAMP(3);        // ranking + counts
         // Stored paths go to the stage sorted by bin inside the tile (through LDS), so that both this write and
         // k_move's read are dense and coalesced and k_move's scattered write falls into per-bin runs.
@@ -713,6 +755,7 @@ struct ptx_tracer {
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
+    uint32_t prim_bits = 0, mesh_bits = 0;               // geoms 0..31 by kind, for the candidate masks
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
@@ -740,7 +783,7 @@ struct ptx_tracer {
     bool cap_filled = false;
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
-        s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0;
+        s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.prim_bits = prim_bits; s.mesh_bits = mesh_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -1045,7 +1088,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // the table goes to LDS when it leaves room for at least 2 workgroups per CU (160 KB LDS, ~19 KB of sort buffers)
     t->tri_lds = (((size_t)t->ntri * 24 + (size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
     // per-geom table for the per-lane gathers (rows 0-2 of the three matrices) and conservative world boxes
-    std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 6, 0.f);
+    std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 8, 0.f);
     for (int i = 0; i < ngeoms; i++) {
         const DGeom &d = hg[i];
         float *o = &hgtab[(size_t)i * 40];
@@ -1055,7 +1098,13 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
                 for (int c = 0; c < 4; c++) o[m * 12 + r * 4 + c] = mats3[m][c * 4 + r];
         int32_t ints[4] = {d.type, d.materialid, d.faceStart, d.faceCount};
         memcpy(o + 36, ints, sizeof ints);
-        make_world_aabb(d, hfaces, &haabb[(size_t)i * 6]);
+        float box[6];
+        make_world_aabb(d, hfaces, box);
+        for (int k = 0; k < 3; k++) { haabb[(size_t)i * 8 + k] = box[k]; haabb[(size_t)i * 8 + 4 + k] = box[3 + k]; }
+        if (i < 32) {
+            if (d.type == G_OBJ) t->mesh_bits |= 1u << i;
+            else if (d.type == G_CUBE || d.type == G_SPHERE) t->prim_bits |= 1u << i;
+        }
     }
     t->cull = (t->tri_lds && ngeoms >= 1 && ngeoms <= 32 && !opt.no_cull) ? 1 : 0;
     if (hfaces.empty()) hfaces.resize(15, 0.f);
