@@ -212,7 +212,7 @@ struct DScene {
     const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
                                         // invTranspose rows 0-2 (12), type, materialid, faceStart, faceCount
     const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box (min xyz, pad, max xyz, pad), or NULL
-    uint32_t prim_bits, mesh_bits;      // bit i: geom i is a cube or sphere / a mesh (geoms of unknown type are in neither)
+    uint32_t cube_bits, sphere_bits, mesh_bits;   // bit i: geom i is a cube / sphere / mesh (unknown types are in none)
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
@@ -536,7 +536,7 @@ PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
 
 // Candidate mask of one ray: bit i set <=> geom i's conservative world box is reached (uniform loop over geoms, two
 // boxes per trip so their scalar loads overlap; 8 floats per box: min xyz, pad, max xyz, pad).  Which of the set bits
-// are cubes/spheres and which are meshes is a per-scene constant (sc.prim_bits / sc.mesh_bits).
+// are cubes, spheres or meshes is a per-scene constant (sc.cube_bits / sphere_bits / mesh_bits).
 PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
     typedef const __attribute__((address_space(4))) float cfloat;
     cfloat *ab = (cfloat *)sc.aabb;

@@ -53,8 +53,8 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
-// tileIntersect's 2 x 3 list counters
-constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 6) + 3) & ~3; }
+// tileIntersect's 2 x 4 list counters
+constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8) + 3) & ~3; }
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
@@ -190,59 +190,82 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
-    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [ITEMS_PER_PASS*TILE]: ray | geom << 8,
-    constexpr int CAP = ITEMS_PER_PASS * TILE;                                     // cubes/spheres from the front, meshes from the back
-    uint32_t prim_mask = 0, mesh_mask = 0;
-    if (alive) { const uint32_t m = cullMask(sc, ray); prim_mask = m & sc.prim_bits; mesh_mask = m & sc.mesh_bits; }
+    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [CAP] ray | geom << 8: cubes from the front,
+    uint16_t *listM = list + ITEMS_PER_PASS * TILE;                                // spheres from the back; [CAP] meshes
+    constexpr int CAP = ITEMS_PER_PASS * TILE;
+    uint32_t cube_mask = 0, sph_mask = 0, mesh_mask = 0;
+    if (alive) {
+        const uint32_t m = cullMask(sc, ray);
+        cube_mask = m & sc.cube_bits; sph_mask = m & sc.sphere_bits; mesh_mask = m & sc.mesh_bits;
+    }
     rayb[0 * TILE + tid] = ray.o.x; rayb[1 * TILE + tid] = ray.o.y; rayb[2 * TILE + tid] = ray.o.z;
     rayb[3 * TILE + tid] = ray.d.x; rayb[4 * TILE + tid] = ray.d.y; rayb[5 * TILE + tid] = ray.d.z;
     best[tid] = KEY_NONE;
     for (;;) {
-        // this pass: up to ITEMS_PER_PASS pairs per ray, cubes/spheres before meshes.  Slots: prefix inside the wave
-        // from ballots of the 3-bit counts, one LDS atomic per wave for its base (tcnt[3q..]: pairs of cubes/spheres,
-        // pairs of meshes, "some ray has more"; the other parity's counters are cleared meanwhile for the next pass).
-        const int cp = (int)__popc(prim_mask), cm = (int)__popc(mesh_mask);
-        const int np = cp < ITEMS_PER_PASS ? cp : ITEMS_PER_PASS;
-        const int nm = cm < ITEMS_PER_PASS - np ? cm : ITEMS_PER_PASS - np;
-        const unsigned long long p0 = __ballot(np & 1), p1 = __ballot(np & 2), p2 = __ballot(np & 4);
-        const unsigned long long m0 = __ballot(nm & 1), m1 = __ballot(nm & 2), m2 = __ballot(nm & 4);
-        const unsigned long long left = __ballot(cp + cm > np + nm);
-        const int exP = wavePrefix(p0, lane) + 2 * wavePrefix(p1, lane) + 4 * wavePrefix(p2, lane);
-        const int exM = wavePrefix(m0, lane) + 2 * wavePrefix(m1, lane) + 4 * wavePrefix(m2, lane);
-        const int wP = __popcll(p0) + 2 * __popcll(p1) + 4 * __popcll(p2);
-        const int wM = __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
-        int baseP = 0, baseM = 0;
-        if (lane == 0) {
-            if (wP) baseP = atomicAdd(&tcnt[3 * q + 0], wP);
-            if (wM) baseM = atomicAdd(&tcnt[3 * q + 1], wM);
-            if (left) tcnt[3 * q + 2] = 1;
+        // this pass: up to ITEMS_PER_PASS pairs per ray -- cubes, then spheres, then meshes, each kind in a run of
+        // its own so that the waves working the list off run one kind of test.  Slots: prefix inside the wave from
+        // ballots of the 3-bit counts, one LDS atomic per wave and kind for its base (tcnt[4q..]: cube, sphere and
+        // mesh pairs, "some ray has more"; the other parity's counters are cleared meanwhile for the next pass).
+        const int cc = (int)__popc(cube_mask), cs = (int)__popc(sph_mask), cm = (int)__popc(mesh_mask);
+        const int nc = cc < ITEMS_PER_PASS ? cc : ITEMS_PER_PASS;
+        const int ns = cs < ITEMS_PER_PASS - nc ? cs : ITEMS_PER_PASS - nc;
+        const int nm = cm < ITEMS_PER_PASS - nc - ns ? cm : ITEMS_PER_PASS - nc - ns;
+        int base[3], tot[3];
+        const int cnt3[3] = {nc, ns, nm};
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const unsigned long long b0 = __ballot(cnt3[kind] & 1), b1 = __ballot(cnt3[kind] & 2), b2 = __ballot(cnt3[kind] & 4);
+            base[kind] = wavePrefix(b0, lane) + 2 * wavePrefix(b1, lane) + 4 * wavePrefix(b2, lane);
+            tot[kind] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
         }
-        baseP = __builtin_amdgcn_readfirstlane(baseP) + exP;
-        baseM = __builtin_amdgcn_readfirstlane(baseM) + exM;
-        for (int j = 0; j < np; j++) {
-            const int g = __ffs((int)prim_mask) - 1;
-            prim_mask &= prim_mask - 1;
-            list[baseP + j] = (uint16_t)(tid | (g << 8));
+        const unsigned long long left = __ballot(cc + cs + cm > nc + ns + nm);
+        int wb0 = 0, wb1 = 0, wb2 = 0;
+        if (lane == 0) {
+            if (tot[0]) wb0 = atomicAdd(&tcnt[4 * q + 0], tot[0]);
+            if (tot[1]) wb1 = atomicAdd(&tcnt[4 * q + 1], tot[1]);
+            if (tot[2]) wb2 = atomicAdd(&tcnt[4 * q + 2], tot[2]);
+            if (left) tcnt[4 * q + 3] = 1;
+        }
+        base[0] += __builtin_amdgcn_readfirstlane(wb0);
+        base[1] += __builtin_amdgcn_readfirstlane(wb1);
+        base[2] += __builtin_amdgcn_readfirstlane(wb2);
+        for (int j = 0; j < nc; j++) {
+            const int g = __ffs((int)cube_mask) - 1;
+            cube_mask &= cube_mask - 1;
+            list[base[0] + j] = (uint16_t)(tid | (g << 8));
+        }
+        for (int j = 0; j < ns; j++) {
+            const int g = __ffs((int)sph_mask) - 1;
+            sph_mask &= sph_mask - 1;
+            list[CAP - 1 - (base[1] + j)] = (uint16_t)(tid | (g << 8));
         }
         for (int j = 0; j < nm; j++) {
             const int g = __ffs((int)mesh_mask) - 1;
             mesh_mask &= mesh_mask - 1;
-            list[CAP - 1 - (baseM + j)] = (uint16_t)(tid | (g << 8));
+            listM[base[2] + j] = (uint16_t)(tid | (g << 8));
         }
         __syncthreads();
-        const int totP = tcnt[3 * q + 0], totM = tcnt[3 * q + 1], more = tcnt[3 * q + 2];
-        if (tid == 0) { tcnt[3 * (q ^ 1) + 0] = 0; tcnt[3 * (q ^ 1) + 1] = 0; tcnt[3 * (q ^ 1) + 2] = 0; }
+        const int totC = tcnt[4 * q + 0], totS = tcnt[4 * q + 1], totM = tcnt[4 * q + 2], more = tcnt[4 * q + 3];
+        if (tid < 4) tcnt[4 * (q ^ 1) + tid] = 0;
         TI_STAMP(5);
 #ifdef PT_STAMPS
-        if (tid == 0) { st_acc[8] += totP; st_acc[9] += totM; st_acc[10] += 1; }
+        if (tid == 0) { st_acc[8] += totC + totS; st_acc[9] += totM; st_acc[10] += 1; }
 #endif
-        for (int k = tid; k < totP + totM; k += TILE) {
-            const int item = k < totP ? list[k] : list[CAP - 1 - (k - totP)], src = item & 0xff, g = item >> 8;
-            Ray r;
-            r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
-            r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
-            const unsigned long long key = k < totP ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r);
-            if (key != KEY_NONE) atomicMin(&best[src], key);
+        // each kind starts on a wave boundary: cubes [0, totC), spheres from roundup64(totC), meshes after them
+        const int startS = (totC + 63) & ~63, startM = startS + ((totS + 63) & ~63);
+        for (int k = tid; k < startM + totM; k += TILE) {
+            int item = -1;
+            if (k < totC) item = list[k];
+            else if (k >= startS && k < startS + totS) item = list[CAP - 1 - (k - startS)];
+            else if (k >= startM) item = listM[k - startM];
+            if (item >= 0) {
+                const int src = item & 0xff, g = item >> 8;
+                Ray r;
+                r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
+                r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
+                const unsigned long long key = k < startM ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r);
+                if (key != KEY_NONE) atomicMin(&best[src], key);
+            }
         }
         __syncthreads();
         q ^= 1;
@@ -267,13 +290,13 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
-    int32_t *tcnt = toff + nb + 1;                                  // tileIntersect's list counters [2][3], zero between uses
+    int32_t *tcnt = toff + nb + 1;                                  // tileIntersect's list counters [2][4], zero between uses
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
     if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
-    if (tid < 6) tcnt[tid] = 0;
+    if (tid < 8) tcnt[tid] = 0;
     __syncthreads();
     const int seg = blockIdx.y;
     const int iter = p.iter + seg;
@@ -324,7 +347,12 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
                 if (p.uses_uv) { h.u = in.u[i]; h.v = in.v[i]; }
                 int mg = in.mg[i];
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
-                Rng rng; rng.seed(iter, in.idx[i], 0);
+                const int sidx = in.idx[i];
+#ifdef PT_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP(11);
+#endif
+                Rng rng; rng.seed(iter, sidx, 0);
                 bool ended = scatterRay(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
                     deposit(p.image, part, pix, ps.color, p.apps);
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     }
 #ifdef PT_STAMPS
     if (lane == 0 && p.stamps)
-        for (int k = 0; k < 11; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
+        for (int k = 0; k < 12; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
 #endif
     for (int b = tid; b < nb; b += TILE) {
         const int ca = run_all[b], cs = run_scat[b];
@@ -755,7 +783,7 @@ struct ptx_tracer {
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
-    uint32_t prim_bits = 0, mesh_bits = 0;               // geoms 0..31 by kind, for the candidate masks
+    uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
@@ -783,7 +811,7 @@ struct ptx_tracer {
     bool cap_filled = false;
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
-        s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.prim_bits = prim_bits; s.mesh_bits = mesh_bits;
+        s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -1103,7 +1131,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         for (int k = 0; k < 3; k++) { haabb[(size_t)i * 8 + k] = box[k]; haabb[(size_t)i * 8 + 4 + k] = box[3 + k]; }
         if (i < 32) {
             if (d.type == G_OBJ) t->mesh_bits |= 1u << i;
-            else if (d.type == G_CUBE || d.type == G_SPHERE) t->prim_bits |= 1u << i;
+            else if (d.type == G_CUBE) t->cube_bits |= 1u << i;
+            else if (d.type == G_SPHERE) t->sphere_bits |= 1u << i;
         }
     }
     t->cull = (t->tri_lds && ngeoms >= 1 && ngeoms <= 32 && !opt.no_cull) ? 1 : 0;
