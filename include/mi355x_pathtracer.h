@@ -96,7 +96,9 @@ typedef struct ptx_options {
                                     albedo AOV (apps/src/pathtrace.cu:412-462, ptx_read_albedo) */
     int32_t no_cull;             /* 1 = every ray tests every geom (the reference's loop) instead of per-lane candidate
                                     lists from conservative world boxes; results are identical either way */
-    int32_t reserved[3];
+    int32_t no_bvh;              /* 1 = every mesh is searched by the reference's loop over all its faces; 0 = meshes of
+                                    24+ faces get a bounding-volume hierarchy (same nearest face, see csrc/pt_bvh.h)      */
+    int32_t reserved[2];
 } ptx_options;
 
 typedef struct ptx_stats {
@@ -181,6 +183,11 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
 /* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
+/* CPU-only (no GPU call): the mesh BVH of csrc/pt_bvh.h against the reference's loop over all faces
+   (src/intersections.h:213-233) on `nrays` object-space rays (6 floats: origin, direction).  stats4 = nodes, leaf
+   triangles, nodes visited in total, 0.  */
+int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, int nrays, int32_t *face_loop, float *t_loop,
+                        int32_t *face_bvh, float *t_bvh, int64_t *stats4);
 int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]);
 /* fields14 (optional): 14 rows of min(n, cap) floats: px py pz (= origin + t*direction, the point that will be
  * shaded) dx dy dz cr cg cb nx ny nz u v (u, v only meaningful when the scene has textures) */

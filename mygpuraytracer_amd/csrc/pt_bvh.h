@@ -1,0 +1,186 @@
+// pt_bvh.h -- bounding-volume hierarchy over the triangles of one OBJ geom (what the reference only gestures at:
+// `//TODO BVH` src/pathtrace.cu:289, BOUNDING_BOX :40,306-311).  It changes WHICH triangles meshIntersectionTest
+// (src/intersections.h:207-233) looks at, never what it computes for one: every visited triangle goes through the
+// same rayTriangle + barycentric point + distance arithmetic, and the winner is the minimum of (distance, face
+// index) -- the reference's strict `t < tmin` in face order.  A subtree is skipped only when the ray misses its box
+// (inflated well beyond fp32 error) or the box starts behind the best hit so far (with slack), so the result equals
+// the brute-force loop's; tests/test_bvh.py checks that on random and grazing rays (CPU, this header compiled for
+// the host) and tests/test_gpu_parity.py against the oracle's brute force on the GPU.
+//
+// The traversal (bvhNearest) lives in pt_device.h next to the triangle test; this header is the host-side builder.
+// Layout ("threaded" preorder, no stack): node = 2 x 16 bytes {lo.xyz, skip}{hi.xyz, leaf}.  skip = the next node
+// when this one is missed or is a leaf (-1 = done); an inner node that is hit continues at n + 1.  leaf = count << 28
+// | first (count 0 = inner).  Leaf triangles are stored in leaf order, 16 floats each: v0, e1, e2 (as tri9), the
+// vertices p1, p2 the reference interpolates the hit point from, and the face index inside the geom.
+#pragma once
+#include "pt_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace ptd {
+
+// ---- host-side builder: binned SAH, leaves of <= BVH_LEAF_MAX triangles ------------------------------------------
+struct BvhBuild {
+    std::vector<BvhQuad> nodes;           // 2 per node, appended to whatever is already there
+    std::vector<float> tris;              // 16 per leaf triangle, appended likewise
+};
+
+namespace bvh_detail {
+struct Prim { double lo[3], hi[3], c[3]; int face; };
+struct Node { double lo[3], hi[3]; int left = -1, right = -1, first = 0, count = 0, size = 1; };
+
+inline void boundsOf(const std::vector<Prim> &pr, int a, int b, double lo[3], double hi[3]) {
+    for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+    for (int i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], pr[i].lo[k]); hi[k] = std::max(hi[k], pr[i].hi[k]); }
+}
+inline double area(const double lo[3], const double hi[3]) {
+    const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+
+inline int buildRec(std::vector<Prim> &pr, std::vector<Node> &out, int a, int b, int depth) {
+    const int id = (int)out.size();
+    out.emplace_back();
+    {
+        Node &nd = out[id];
+        boundsOf(pr, a, b, nd.lo, nd.hi);
+    }
+    const int n = b - a;
+    if (n <= BVH_LEAF_MAX || depth > 48) {
+        // (depth guard: more than BVH_LEAF_MAX triangles may end in one leaf only if count still fits 4 bits)
+        if (n <= 15) { out[id].first = a; out[id].count = n; return id; }
+    }
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (int i = a; i < b; i++)
+        for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], pr[i].c[k]); chi[k] = std::max(chi[k], pr[i].c[k]); }
+    constexpr int NB = 16;
+    double bestCost = 1e300;
+    int bestAxis = -1, bestBin = -1;
+    for (int ax = 0; ax < 3; ax++) {
+        const double ext = chi[ax] - clo[ax];
+        if (!(ext > 0.0)) continue;
+        int cnt[NB] = {0};
+        double blo[NB][3], bhi[NB][3];
+        for (int q = 0; q < NB; q++) for (int k = 0; k < 3; k++) { blo[q][k] = 1e300; bhi[q][k] = -1e300; }
+        for (int i = a; i < b; i++) {
+            int q = (int)((pr[i].c[ax] - clo[ax]) / ext * NB);
+            q = std::min(std::max(q, 0), NB - 1);
+            cnt[q]++;
+            for (int k = 0; k < 3; k++) { blo[q][k] = std::min(blo[q][k], pr[i].lo[k]); bhi[q][k] = std::max(bhi[q][k], pr[i].hi[k]); }
+        }
+        double rArea[NB]; int rCnt[NB];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        int c = 0;
+        for (int q = NB - 1; q >= 1; q--) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[q][k]); hi[k] = std::max(hi[k], bhi[q][k]); }
+            c += cnt[q];
+            rArea[q] = c ? area(lo, hi) : 0.0; rCnt[q] = c;
+        }
+        for (int k = 0; k < 3; k++) { lo[k] = 1e300; hi[k] = -1e300; }
+        c = 0;
+        for (int q = 0; q < NB - 1; q++) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[q][k]); hi[k] = std::max(hi[k], bhi[q][k]); }
+            c += cnt[q];
+            if (c == 0 || rCnt[q + 1] == 0) continue;
+            const double cost = area(lo, hi) * c + rArea[q + 1] * rCnt[q + 1];
+            if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = q; }
+        }
+    }
+    int mid;
+    if (bestAxis >= 0) {
+        const double ext = chi[bestAxis] - clo[bestAxis], lo0 = clo[bestAxis];
+        const int ax = bestAxis, bb = bestBin;
+        auto it = std::stable_partition(pr.begin() + a, pr.begin() + b, [&](const Prim &p) {
+            int q = (int)((p.c[ax] - lo0) / ext * NB);
+            q = std::min(std::max(q, 0), NB - 1);
+            return q <= bb;
+        });
+        mid = (int)(it - pr.begin());
+    } else {
+        mid = a + n / 2;                  // all centroids coincide: split by position in the list
+    }
+    if (mid <= a || mid >= b) mid = a + n / 2;
+    const int l = buildRec(pr, out, a, mid, depth + 1);
+    const int r = buildRec(pr, out, mid, b, depth + 1);
+    out[id].left = l; out[id].right = r; out[id].size = 1 + out[l].size + out[r].size;
+    return id;
+}
+}  // namespace bvh_detail
+
+// Appends the tree of faces [faceStart, faceStart + faceCount) (15 floats each: 3 x (pos xyz, uv)) to `out`;
+// tri9 holds v0, e1, e2 per face as uploaded for the plain loop.  Returns the root's node index.
+inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int faceCount, BvhBuild &out) {
+    using namespace bvh_detail;
+    std::vector<Prim> pr((size_t)faceCount);
+    for (int j = 0; j < faceCount; j++) {
+        const float *f = faces15 + (size_t)(faceStart + j) * 15;
+        Prim &p = pr[j];
+        p.face = j;
+        for (int k = 0; k < 3; k++) {
+            const double a = f[k], b = f[5 + k], c = f[10 + k];
+            p.lo[k] = std::min(a, std::min(b, c)); p.hi[k] = std::max(a, std::max(b, c));
+            p.c[k] = (a + b + c) / 3.0;
+            if (!(p.lo[k] == p.lo[k]) || !(p.hi[k] == p.hi[k])) { p.lo[k] = -1e30; p.hi[k] = 1e30; p.c[k] = 0.0; }   // NaN vertex: never culled
+        }
+    }
+    std::vector<Node> tree;
+    tree.reserve((size_t)faceCount * 2);
+    buildRec(pr, tree, 0, faceCount, 0);
+    double mdiag = 0.0;
+    for (int k = 0; k < 3; k++) mdiag += (tree[0].hi[k] - tree[0].lo[k]) * (tree[0].hi[k] - tree[0].lo[k]);
+    mdiag = std::sqrt(mdiag);
+    const int base = (int)(out.nodes.size() / 2), tbase = (int)(out.tris.size() / 16);
+    out.nodes.resize(out.nodes.size() + 2 * tree.size());
+    // preorder == creation order of buildRec (node, left subtree, right subtree), so node i sits at base + i
+    std::vector<int> skip(tree.size(), -1);
+    for (size_t i = 0; i < tree.size(); i++)
+        if (tree[i].count == 0) { skip[tree[i].left] = base + tree[i].right; skip[tree[i].right] = skip[i]; }
+    for (size_t i = 0; i < tree.size(); i++) {
+        const Node &nd = tree[i];
+        double diag = 0.0;
+        for (int k = 0; k < 3; k++) diag += (nd.hi[k] - nd.lo[k]) * (nd.hi[k] - nd.lo[k]);
+        const double m = 2e-3 * std::sqrt(diag) + 1e-5 * mdiag + 1e-30;
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = nextafterf((float)(nd.lo[k] - m), -INFINITY);
+            hi[k] = nextafterf((float)(nd.hi[k] + m), INFINITY);
+        }
+        BvhQuad A{lo[0], lo[1], lo[2], skip[i]};
+        BvhQuad B{hi[0], hi[1], hi[2], nd.count ? (int32_t)(((uint32_t)nd.count << 28) | (uint32_t)(tbase + nd.first)) : 0};
+        out.nodes[2 * (base + i)] = A; out.nodes[2 * (base + i) + 1] = B;
+    }
+    out.tris.resize(out.tris.size() + (size_t)faceCount * 16);
+    for (int i = 0; i < faceCount; i++) {
+        const int j = pr[i].face;
+        const float *f = faces15 + (size_t)(faceStart + j) * 15, *t9 = tri9 + (size_t)(faceStart + j) * 9;
+        float *o = &out.tris[(size_t)(tbase + i) * 16];
+        for (int k = 0; k < 9; k++) o[k] = t9[k];
+        for (int k = 0; k < 3; k++) { o[9 + k] = f[5 + k]; o[12 + k] = f[10 + k]; }
+        memcpy(&o[15], &j, 4);
+    }
+    return base;
+}
+
+// The reference's loop over all faces (src/intersections.h:213-233) on the host, for the CPU check of the tree.
+inline float loopNearestHost(const float *faces15, const float *tri9, int nfaces, vec3 o, vec3 d, int &face) {
+    float tmin = 3.402823466e+38f;
+    face = -1;
+    for (int j = 0; j < nfaces; j++) {
+        const float *t9 = tri9 + (size_t)j * 9, *f = faces15 + (size_t)j * 15;
+        const vec3 v0 = V3(t9[0], t9[1], t9[2]), e1 = V3(t9[3], t9[4], t9[5]), e2 = V3(t9[6], t9[7], t9[8]);
+        float b0, b1;
+        if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {
+            const vec3 p1 = V3(f[5], f[6], f[7]), p2 = V3(f[10], f[11], f[12]);
+            const float w = 1 - b0 - b1;
+            const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
+            const float t = length(sub(o, p));
+            if (t < tmin) { tmin = t; face = j; }
+        }
+    }
+    return tmin;
+}
+
+}  // namespace ptd

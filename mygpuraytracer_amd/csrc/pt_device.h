@@ -15,26 +15,27 @@
 #include <stdint.h>
 
 #define PT_DEV __device__ __forceinline__
+#define PT_HD __host__ __device__ __forceinline__      // also compiled for the host (BVH checks on the CPU, pt_bvh.h)
 
 namespace ptd {
 
 struct vec3 { float x, y, z; };
 
-PT_DEV vec3 V3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
-PT_DEV vec3 add(vec3 a, vec3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
-PT_DEV vec3 sub(vec3 a, vec3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
-PT_DEV vec3 mul(vec3 a, vec3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
-PT_DEV vec3 scale(vec3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
-PT_DEV vec3 neg(vec3 a) { return V3(-a.x, -a.y, -a.z); }
+PT_HD vec3 V3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD vec3 add(vec3 a, vec3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD vec3 sub(vec3 a, vec3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD vec3 mul(vec3 a, vec3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD vec3 scale(vec3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+PT_HD vec3 neg(vec3 a) { return V3(-a.x, -a.y, -a.z); }
 // glm dot(vec3): tmp = x*y; tmp.x + tmp.y + tmp.z   (glm/detail/func_geometric.inl:65-72)
-PT_DEV float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_HD float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // glm cross (func_geometric.inl:134-141)
-PT_DEV vec3 cross(vec3 x, vec3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+PT_HD vec3 cross(vec3 x, vec3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 // glm normalize = x * (1 / sqrt(dot(x,x)))  (func_geometric.inl:154-159, func_exponential.inl:62-68)
-PT_DEV vec3 normalize(vec3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
-PT_DEV float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
-PT_DEV float fmin_glm(float x, float y) { return x < y ? x : y; }   // glm min: x < y ? x : y
-PT_DEV float fmax_glm(float x, float y) { return x > y ? x : y; }   // glm max: x > y ? x : y
+PT_HD vec3 normalize(vec3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
+PT_HD float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
+PT_HD float fmin_glm(float x, float y) { return x < y ? x : y; }   // glm min: x < y ? x : y
+PT_HD float fmax_glm(float x, float y) { return x > y ? x : y; }   // glm max: x > y ? x : y
 
 // multiplyMV (src/intersections.h:34-36): xyz of mat4*vec4, glm column-major m[c*4+r]
 PT_DEV vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
@@ -198,6 +199,9 @@ struct DCamera {                        // = struct Camera, src/sceneStructs.h:8
     int32_t resx, resy;
     float position[3], lookAt[3], view[3], up[3], right[3], fov[2], pixelLength[2];
 };
+struct alignas(16) BvhQuad { float x, y, z; int32_t w; };
+constexpr int BVH_LEAF_MAX = 4;
+constexpr int BVH_MIN_FACES = 24;        // meshes smaller than this keep the plain loop
 struct DScene {
     const DGeom *__restrict__ geoms;
     const DMaterial *__restrict__ mats;
@@ -207,16 +211,20 @@ struct DScene {
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
     int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS
-                                        // (pt_lds): tri9 [ntri*9], faces [ntri*15], materials [nmats*11], gtab [ngeoms*40]
+                                        // (pt_lds): tri9 [ntri_lds*9], faces [ntri_lds*15], materials [nmats*11], gtab [ngeoms*40]
     int32_t ntri;
+    int32_t ntri_lds;                   // triangles staged with them: ntri, or 0 when the mesh tables stay in global memory
     const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
                                         // invTranspose rows 0-2 (12), type, materialid, faceStart, faceCount
     const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box (min xyz, pad, max xyz, pad), or NULL
     uint32_t cube_bits, sphere_bits, mesh_bits;   // bit i: geom i is a cube / sphere / mesh (unknown types are in none)
+    const BvhQuad *__restrict__ bvh_nodes;          // threaded BVH of the larger meshes (pt_bvh.h), or NULL
+    const float *__restrict__ bvh_tris;             // 16 floats per leaf triangle
+    const int32_t *__restrict__ bvh_root;           // per geom: root node, -1 = plain loop over its faces
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
-PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri * 24 + sc.nmats * 11 + sc.ngeoms * 40 + 3) & ~3; }
+PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri_lds * 24 + sc.nmats * 11 + sc.ngeoms * 40 + 3) & ~3; }
 constexpr int GTAB_WORDS = 40;
 
 // dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]
@@ -225,7 +233,7 @@ extern __shared__ __attribute__((aligned(16))) int32_t pt_lds[];
 // Copies the scene tables into LDS (call from every thread of the workgroup, then __syncthreads()).
 __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int nthreads) {
     float *l = reinterpret_cast<float *>(pt_lds);
-    const int n9 = sc.ntri * 9, n15 = sc.ntri * 15, nm = sc.nmats * 11;
+    const int n9 = sc.ntri_lds * 9, n15 = sc.ntri_lds * 15, nm = sc.nmats * 11;
     for (int k = tid; k < n9; k += nthreads) l[k] = sc.tri9[k];
     for (int k = tid; k < n15; k += nthreads) l[n9 + k] = sc.faces[k];
     const float *m = reinterpret_cast<const float *>(sc.mats);
@@ -238,7 +246,7 @@ __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int n
 PT_DEV DMaterial getMaterial(const DScene &sc, int id) {
     DMaterial m;
     if (sc.tri_lds) {
-        const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + id * 11;
+        const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + id * 11;
         m.color[0] = l[0]; m.color[1] = l[1]; m.color[2] = l[2]; m.exponent = l[3];
         m.speccolor[0] = l[4]; m.speccolor[1] = l[5]; m.speccolor[2] = l[6];
         m.hasReflective = l[7]; m.hasRefractive = l[8]; m.ior = l[9]; m.emittance = l[10];
@@ -249,7 +257,7 @@ PT_DEV DMaterial getMaterial(const DScene &sc, int id) {
 }
 // word k of the 15-float record (3 x pos xyz, uv) of triangle `face` (global index)
 PT_DEV float faceWord(const DScene &sc, int face, int k) {
-    if (sc.tri_lds) return reinterpret_cast<const float *>(pt_lds)[sc.ntri * 9 + face * 15 + k];
+    if (sc.tri_lds && sc.ntri_lds) return reinterpret_cast<const float *>(pt_lds)[sc.ntri_lds * 9 + face * 15 + k];
     return sc.faces[(size_t)face * 15 + k];
 }
 PT_DEV vec3 faceVec(const DScene &sc, int face, int k) { return V3(faceWord(sc, face, k), faceWord(sc, face, k + 1), faceWord(sc, face, k + 2)); }
@@ -359,7 +367,7 @@ PT_DEV vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
 
 // One triangle of glm::intersectRayTriangle (glm/gtx/intersect.inl:37-74, single sided: a < epsilon => miss) with
 // e1 = v1 - v0 and e2 = v2 - v0 taken from the upload-time table.
-PT_DEV bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &bx, float &by) {
+PT_HD bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &bx, float &by) {
     vec3 p = cross(dir, e2);
     float a = dot(e1, p);
     if (a < 1.1920928955078125e-07f) return false;     // FLT_EPSILON
@@ -376,17 +384,78 @@ PT_DEV bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &b
     return bz >= 0.0f;
 }
 
+// ---- BVH traversal (builder and layout: pt_bvh.h) ------------------------------------------------------------------
+
+// Nearest face of the mesh whose tree starts at node `root`, object-space ray (o, d normalised as the reference
+// does).  Returns the object-space distance (FLT_MAX: none); face = index inside the geom, b0/b1 = its barycentrics.
+PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restrict__ tris, int root, vec3 o, vec3 d,
+                       int &face, float &b0o, float &b1o, int *visited = nullptr) {
+    const float tiny = 1e-20f;
+    const float ddx = __builtin_fabsf(d.x) < tiny ? __builtin_copysignf(tiny, d.x) : d.x;
+    const float ddy = __builtin_fabsf(d.y) < tiny ? __builtin_copysignf(tiny, d.y) : d.y;
+    const float ddz = __builtin_fabsf(d.z) < tiny ? __builtin_copysignf(tiny, d.z) : d.z;
+    const float ix = 1.0f / ddx, iy = 1.0f / ddy, iz = 1.0f / ddz;
+    float tmin = 3.402823466e+38f;
+    face = -1; b0o = 0.f; b1o = 0.f;
+    int n = root;
+    while (n >= 0) {
+        const BvhQuad A = nodes[2 * n], B = nodes[2 * n + 1];
+        const float x0 = (A.x - o.x) * ix, x1 = (B.x - o.x) * ix;
+        const float y0 = (A.y - o.y) * iy, y1 = (B.y - o.y) * iy;
+        const float z0 = (A.z - o.z) * iz, z1 = (B.z - o.z) * iz;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        // any NaN => visit.  The hit point of a triangle in this box lies on the ray at a parameter >= tn, and its
+        // distance is that parameter up to rounding, so a box that starts beyond the best distance cannot improve it.
+        const bool skip = (tf < tn) || (tf < 0.0f) || (tn > tmin * 1.0001f);
+        if (visited) ++*visited;
+        if (skip) { n = A.w; continue; }
+        const int count = (int)((uint32_t)B.w >> 28), first = B.w & 0x0fffffff;
+        if (count == 0) { n = n + 1; continue; }
+        for (int k = 0; k < count; k++) {
+            const float *T = tris + (size_t)(first + k) * 16;
+            const vec3 v0 = V3(T[0], T[1], T[2]), e1 = V3(T[3], T[4], T[5]), e2 = V3(T[6], T[7], T[8]);
+            float b0, b1;
+            if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {
+                const vec3 p1 = V3(T[9], T[10], T[11]), p2 = V3(T[12], T[13], T[14]);
+                const float w = 1 - b0 - b1;
+                const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
+                const float t = length(sub(o, p));
+                int f;
+                __builtin_memcpy(&f, &T[15], 4);
+                if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }
+            }
+        }
+        n = A.w;
+    }
+    return tmin;
+}
+
 // meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space
 // distance, as the reference does.  (intersectionPoint, which the reference also fills, has no reader.)
-PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c) {
+PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, int bvhRoot = -1) {
     Ray q;
     q.o = multiplyMV(geom.inv, r.o, 1.0f);
     q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
     float tmin = 3.402823466e+38f;     // FLT_MAX
     int nearest = -1;
+    if (bvhRoot >= 0) {
+        // same per-triangle arithmetic, same winner (nearest distance, lowest face index): see pt_bvh.h
+        float b0, b1;
+        tmin = bvhNearest(sc.bvh_nodes, sc.bvh_tris, bvhRoot, q.o, q.d, nearest, b0, b1);
+        if (nearest >= 0) {
+            const int f = geom.faceStart + nearest;
+            const float w = 1 - b0 - b1;
+            c.u = (w * faceWord(sc, f, 3) + b0 * faceWord(sc, f, 8)) + b1 * faceWord(sc, f, 13);
+            c.v = (w * faceWord(sc, f, 4) + b0 * faceWord(sc, f, 9)) + b1 * faceWord(sc, f, 14);
+        }
+        c.face = nearest;
+        if (nearest == -1) return -1.f;
+        return tmin;
+    }
     for (int j = 0; j < geom.faceCount; j++) {
         vec3 v0, e1, e2;
-        if (sc.tri_lds) {             // broadcast ds_reads: every lane reads the same triangle
+        if (sc.tri_lds && sc.ntri_lds) {      // broadcast ds_reads: every lane reads the same triangle
             const float *t9 = reinterpret_cast<const float *>(pt_lds) + (size_t)(geom.faceStart + j) * 9;
             v0 = V3(t9[0], t9[1], t9[2]); e1 = V3(t9[3], t9[4], t9[5]); e2 = V3(t9[6], t9[7], t9[8]);
         } else {
@@ -495,7 +564,7 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
         bool tested = true;
         if (geom.type == G_CUBE) t = boxTestCore(geom, ray, c);
         else if (geom.type == G_SPHERE) t = sphereTestCore(geom, ray, c);
-        else if (geom.type == G_OBJ) { t = meshTestCore(sc, geom, ray, c); tmp_u = c.u; tmp_v = c.v; }
+        else if (geom.type == G_OBJ) { t = meshTestCore(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[i] : -1); tmp_u = c.u; tmp_v = c.v; }
         else tested = false;    // TRIANGLE has no test routine in the reference: t keeps a value that never wins
         if (tested && t > 0.0f && t_min > t) {
             t_min = t;
@@ -654,7 +723,7 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
     geom.faceStart = __float_as_int(G[38]); geom.faceCount = __float_as_int(G[39]);
     Cand c;
     c.face = -1; c.u = 0.f; c.v = 0.f;
-    const float t = meshTestCore(sc, geom, ray, c);
+    const float t = meshTestCore(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1);
     if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
     return packKey(t, g, (uint32_t)c.face);
 }
@@ -736,9 +805,9 @@ PT_DEV float sphereIntersectionTest(const DGeom &g, Ray r, vec3 &point, vec3 &no
     return t;
 }
 PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &g, Ray r, vec3 &point, vec3 &normal, float &u, float &v,
-                                  bool &outside) {
+                                  bool &outside, int bvhRoot = -1) {
     Cand c; c.face = -1; c.u = u; c.v = v;
-    float t = meshTestCore(sc, g, r, c);
+    float t = meshTestCore(sc, g, r, c, bvhRoot);
     u = c.u; v = c.v;
     if (t != -1.f) {
         Ray q;                                      // src/intersections.h:235,241 (the unused intersectionPoint)

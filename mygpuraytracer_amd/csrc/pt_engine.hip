@@ -32,6 +32,7 @@
 
 #include "../../include/mi355x_pathtracer.h"
 #include "pt_device.h"
+#include "pt_bvh.h"
 
 using namespace ptd;
 
@@ -187,7 +188,7 @@ constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contri
 #endif
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
                                               int32_t *tcnt, int &q, int tid, int lane, int wave TI_ARGS) {
-    const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri * 24 + sc.nmats * 11;
+    const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
     uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [CAP] ray | geom << 8: cubes from the front,
@@ -675,7 +676,7 @@ __global__ void k_kat_geom(DScene sc, int gi, int n, const float *rays, float *o
     float t = -1.f;
     if (g.type == G_CUBE) t = boxIntersectionTest(g, r, p, nrm, outside);
     else if (g.type == G_SPHERE) t = sphereIntersectionTest(g, r, p, nrm, outside);
-    else if (g.type == G_OBJ) t = meshIntersectionTest(sc, g, r, p, nrm, u, v, outside);
+    else if (g.type == G_OBJ) t = meshIntersectionTest(sc, g, r, p, nrm, u, v, outside, sc.bvh_root ? sc.bvh_root[gi] : -1);
     float *o = out + i * 10;
     o[0] = t; o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = nrm.x; o[5] = nrm.y; o[6] = nrm.z; o[7] = u; o[8] = v;
     o[9] = outside ? 1.f : 0.f;
@@ -784,6 +785,8 @@ struct ptx_tracer {
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
+    BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr;   // pt_bvh.h (NULL: no mesh has one)
+    int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
@@ -812,6 +815,7 @@ struct ptx_tracer {
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
+        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.ntri_lds = 0;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -870,7 +874,7 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
@@ -888,7 +892,7 @@ int free_tracer(ptx_tracer *t) {
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
 int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
     const int nb = t->nbins;
-    const int triWords = t->tri_lds ? ((t->ntri * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
+    const int triWords = t->tri_lds ? ((t->ntri_lds * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
@@ -941,7 +945,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
             continue;
         }
         BounceParams bp;
-        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
+        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
         const bool from_cache = (b == 1 && cache_on);           // with the cache on, bounce 0 always lands in soa[2]
         bp.in = from_cache ? t->soa[2] : t->soa[0];
         bp.stage = t->soa[1];
@@ -1113,8 +1117,29 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         float *o = &htri9[(size_t)j * 9];
         for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
     }
-    // the table goes to LDS when it leaves room for at least 2 workgroups per CU (160 KB LDS, ~19 KB of sort buffers)
-    t->tri_lds = (((size_t)t->ntri * 24 + (size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    // a BVH for every mesh with enough faces to repay it (pt_bvh.h); its nodes and leaf triangles stay in global memory
+    {
+        BvhBuild bb;
+        std::vector<int32_t> roots((size_t)std::max(ngeoms, 1), -1);
+        for (int i = 0; i < ngeoms; i++)
+            if (hg[i].type == G_OBJ && hg[i].faceCount >= BVH_MIN_FACES && !opt.no_bvh) {
+                roots[i] = bvhBuild(hfaces.data(), htri9.data(), hg[i].faceStart, hg[i].faceCount, bb);
+                t->bvh_meshes++;
+            }
+        t->bvh_nodes = (int)(bb.nodes.size() / 2);
+        if (t->bvh_meshes) {
+            HC(hipMalloc(&t->d_bvh_nodes, sizeof(BvhQuad) * bb.nodes.size()));
+            HC(hipMemcpy(t->d_bvh_nodes, bb.nodes.data(), sizeof(BvhQuad) * bb.nodes.size(), hipMemcpyHostToDevice));
+            HC(hipMalloc(&t->d_bvh_tris, sizeof(float) * bb.tris.size()));
+            HC(hipMemcpy(t->d_bvh_tris, bb.tris.data(), sizeof(float) * bb.tris.size(), hipMemcpyHostToDevice));
+            HC(hipMalloc(&t->d_bvh_root, sizeof(int32_t) * roots.size()));
+            HC(hipMemcpy(t->d_bvh_root, roots.data(), sizeof(int32_t) * roots.size(), hipMemcpyHostToDevice));
+        }
+    }
+    // materials and geom tables go to LDS; the triangle tables join them when that leaves room for at least 2 workgroups
+    // per CU (160 KB LDS, ~19 KB of sort buffers) -- otherwise they are read from global memory (L2-resident)
+    t->tri_lds = (((size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    t->ntri_lds = (t->tri_lds && ((size_t)t->ntri * 24 + (size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024) ? t->ntri : 0;
     // per-geom table for the per-lane gathers (rows 0-2 of the three matrices) and conservative world boxes
     std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 8, 0.f);
     for (int i = 0; i < ngeoms; i++) {
@@ -1470,6 +1495,35 @@ int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_b
 }
 
 // diagnostic build (-DPT_STAMPS): cycles per phase of k_bounce summed over waves: [0..4] first bounce, [8..12] later bounces
+// CPU-only check of the mesh BVH: builds the tree of `nfaces` faces and searches `nrays` object-space rays (origin,
+// direction; the direction is normalised the way meshIntersectionTest does) with the tree and with the plain loop.
+int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, int nrays, int32_t *face_loop, float *t_loop,
+                        int32_t *face_bvh, float *t_bvh, int64_t *stats4) {
+    if (!faces15 || !rays6 || !face_loop || !t_loop || !face_bvh || !t_bvh || nfaces < 1 || nrays < 0)
+        return set_error(PTX_ERR_INVALID, "ptx_debug_bvh_check: bad argument");
+    std::vector<float> tri9((size_t)nfaces * 9);
+    for (int j = 0; j < nfaces; j++) {
+        const float *f = faces15 + (size_t)j * 15;
+        float *o = &tri9[(size_t)j * 9];
+        for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
+    }
+    BvhBuild bb;
+    const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb);
+    long long visited = 0;
+    for (int i = 0; i < nrays; i++) {
+        const vec3 o = V3(rays6[i * 6 + 0], rays6[i * 6 + 1], rays6[i * 6 + 2]);
+        const vec3 d = normalize(V3(rays6[i * 6 + 3], rays6[i * 6 + 4], rays6[i * 6 + 5]));
+        int f0, f1, vis = 0;
+        float b0, b1;
+        t_loop[i] = loopNearestHost(faces15, tri9.data(), nfaces, o, d, f0);
+        t_bvh[i] = bvhNearest(bb.nodes.data(), bb.tris.data(), root, o, d, f1, b0, b1, &vis);
+        face_loop[i] = f0; face_bvh[i] = f1;
+        visited += vis;
+    }
+    if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / 16); stats4[2] = visited; stats4[3] = 0; }
+    return PTX_OK;
+}
+
 int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]) {
     if (!t || !out32) return set_error(PTX_ERR_INVALID, "null argument");
     memset(out32, 0, sizeof(unsigned long long) * 32);

@@ -50,7 +50,8 @@ def dump_from_golden(g, cam="cam_floats_runcuda", res=None):
 
 def ensure_standin_assets():
     """The stand-in mesh's procedural textures are generated (deterministically) rather than committed."""
-    if not os.path.exists(os.path.join(ROOT, "textures", "standin_kd.ppm")):
+    if not os.path.exists(os.path.join(ROOT, "textures", "standin_kd.ppm")) or \
+            not os.path.exists(os.path.join(ROOT, "models", "standin_ship_20k.obj")):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import make_standin_mesh
         make_standin_mesh.main(128)

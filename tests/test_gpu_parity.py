@@ -74,6 +74,8 @@ def test_intersection_kats_on_device(gpu_product, O, scene):
     ("cornellGlass.txt", (96, 54), 12, dict(depth_of_field=1)),
     ("cornellObj.txt", (96, 54), 8, {}),
     ("cornellSpaceship.txt", (96, 54), 8, dict(depth_of_field=1)),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(no_bvh=1)),
+    ("cornellSpaceship20k.txt", (160, 90), 8, {}),                     # 20448 triangles through the BVH vs the oracle's loop
 ])
 def test_stage_parity(gpu_product, O, scene, res, depth, opt):
     """generateRayFromCamera, computeIntersections and shadeFakeMaterial one at a time on identical inputs."""
@@ -150,6 +152,9 @@ def oracle_pending_stream(O, it, bounce):
     ("cornellSpaceship.txt", (96, 54), 8, dict(depth_of_field=1)),
     ("cornellSpaceship.txt", (96, 54), 8, dict(no_lds_triangles=1)),
     ("cornellSpaceship.txt", (96, 54), 8, dict(no_cull=1)),
+    ("cornellSpaceship.txt", (96, 54), 8, dict(no_bvh=1)),                 # the reference's loop over all faces
+    ("cornellSpaceship20k.txt", (64, 36), 8, dict(depth_of_field=1)),      # 20448 triangles: BVH, tables in global memory
+    ("cornellSpaceship20k.txt", (64, 36), 8, dict(no_cull=1)),
     ("cornellGlass.txt", (96, 54), 12, dict(no_cull=1)),
 ])
 def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RINGS, SEGS = 10, 16
 
 
-def mesh_text():
+def mesh_text(RINGS=RINGS, SEGS=SEGS):
     out = ["# procedural stand-in mesh: a pinched ellipsoid hull, %d x %d patches" % (RINGS, SEGS), "mtllib standin_ship.mtl", ""]
     verts, uvs = [], []
     for r in range(RINGS + 1):
@@ -100,11 +100,14 @@ def write_ppm(path, img):
         f.write(np.ascontiguousarray(img).tobytes())
 
 
-def main(size=256, root=ROOT):
+def main(size=256, root=ROOT, big=True):
     os.makedirs(os.path.join(root, "models", "materials"), exist_ok=True)
     os.makedirs(os.path.join(root, "textures"), exist_ok=True)
     with open(os.path.join(root, "models", "standin_ship.obj"), "w") as f:
         f.write(mesh_text())
+    if big:     # the same hull at 72 x 144 patches = 20448 triangles (generated, not committed): the BVH-sized mesh
+        with open(os.path.join(root, "models", "standin_ship_20k.obj"), "w") as f:
+            f.write(mesh_text(72, 144))
     with open(os.path.join(root, "models", "materials", "standin_ship.mtl"), "w") as f:
         f.write(MTL)
     for k, img in textures(size).items():
