@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks: the frame is then reduced through host memory)")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
+                    help="N > 1: 'tiles' = interleaved pixel-row blocks per rank (what north_star prescribes, the default); "
+                    "'iterations' = every rank traces the full frame for every N-th iteration (sums to the single-GPU frame)")
     args = ap.parse_args()
 
     import torch
@@ -103,9 +106,19 @@ def main():
     W, H = RES
     image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
     kw = dict(device=dev_index)
-    if world > 1:
+    by_iter = world > 1 and args.shard == "iterations"
+    if world > 1 and not by_iter:
         kw.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
     T = pt.Tracer(scene, external_image_ptr=image.data_ptr(), **kw)
+
+    def render_steps(first, count):
+        """this rank's part of iterations first .. first+count-1"""
+        if by_iter:
+            f, n = multigpu.iteration_share(first, count, rank, world)
+            if n:
+                T.render(f, n, stride=world)
+        else:
+            T.render(first, count)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,7 +133,7 @@ def main():
     rays0 = T.stats()["rays_total"]
     barrier()
     t0 = time.perf_counter()
-    T.render(args.warmup + 1, args.steps)           # EXACTLY K steps, enqueued back to back on the tracer's stream
+    render_steps(args.warmup + 1, args.steps)       # EXACTLY K steps, enqueued back to back on the tracer's stream
     T.synchronize()
     if world > 1:                                   # one RCCL reduce of the accumulation buffer per run
         reduce_frame(image)
@@ -135,7 +148,7 @@ def main():
 
     # roofline leg: the same K steps again with hipEvents around every launch (on the tracer's stream)
     T.set_kernel_timing(True)
-    T.render(args.warmup + args.steps + 1, args.steps)
+    render_steps(args.warmup + args.steps + 1, args.steps)
     kt = T.kernel_times()
     T.set_kernel_timing(False)
     st2 = T.stats()
@@ -162,7 +175,7 @@ def main():
                     frac=achieved / HBM_PEAK, traffic=traffic,
                     avg_launch_us=avg_s * 1e6, launches=dom_n, units_per_launch=units,
                     algorithmic_bytes_per_unit=BYTES_BOUNCE_KERNEL,
-                    loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / HBM_PEAK, bytes_per_ray=BYTES_LOOP,
+                    loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / (HBM_PEAK * world), bytes_per_ray=BYTES_LOOP,
                               loop_ms_per_step=loop_ms / args.steps),
                     kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()})
 
@@ -170,7 +183,9 @@ def main():
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
                config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb,
-                           parallelism=("1 GPU" if world == 1 else "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL reduce/run" % (world, multigpu.TILE_ROWS))),
+                           parallelism=("1 GPU" if world == 1 else
+                                        "%d ranks taking turns over the iterations of the full frame + 1 RCCL reduce/run" % world if by_iter else
+                                        "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL reduce/run" % (world, multigpu.TILE_ROWS))),
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)

@@ -152,9 +152,14 @@ int ptx_reset_image(ptx_tracer *t);
 int ptx_iterate(ptx_tracer *t, int iter);
 /* iterations iter_first .. iter_first+count-1 back to back, no host round trip in between */
 int ptx_render(ptx_tracer *t, int iter_first, int count);
+/* iterations iter_first, iter_first+stride, ... (count of them): N ranks that take turns over the iterations of one
+ * full frame (rank r: iter_first = r+1, stride = N) and sum their buffers reproduce the single-GPU frame, which
+ * pixel-row tiles cannot (the shading RNG is seeded by stream position) */
+int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride);
 int ptx_synchronize(ptx_tracer *t);
 
 int ptx_read_image(ptx_tracer *t, float *host_rgb);     /* W*H*3 floats = sum over iterations (state.image) */
+int ptx_write_image(ptx_tracer *t, const float *host_rgb);  /* the reverse: resume from a saved accumulation buffer   */
 int ptx_read_albedo(ptx_tracer *t, float *host_rgb);    /* RenderState.albedo of apps/src (apps_variant only)  */
 /* sendToGPU, apps/src/pathtrace.h:10: a finished (e.g. denoised) host frame -> 8-bit preview, no division by iter */
 int ptx_write_denoised_pbo(ptx_tracer *t, const float *host_rgb, uint8_t *host_rgba);

@@ -114,6 +114,8 @@ def load_library():
     L.ptx_reset_image.restype, L.ptx_reset_image.argtypes = i, [vp]
     L.ptx_iterate.restype, L.ptx_iterate.argtypes = i, [vp, i]
     L.ptx_render.restype, L.ptx_render.argtypes = i, [vp, i, i]
+    L.ptx_render_strided.restype, L.ptx_render_strided.argtypes = i, [vp, i, i, i]
+    L.ptx_write_image.restype, L.ptx_write_image.argtypes = i, [vp, vp]
     L.ptx_synchronize.restype, L.ptx_synchronize.argtypes = i, [vp]
     L.ptx_read_image.restype, L.ptx_read_image.argtypes = i, [vp, vp]
     L.ptx_device_image.restype, L.ptx_device_image.argtypes = vp, [vp]
@@ -303,9 +305,44 @@ class Tracer:
         self.iteration = iteration
         return self.read_image() if read_image else None
 
-    def render(self, iter_first, count):
-        _check(self.lib.ptx_render(self.h, iter_first, count), "ptx_render")
-        self.iteration = iter_first + count - 1
+    def render(self, iter_first, count, stride=1):
+        """iterations iter_first, iter_first + stride, ... (count of them), no host round trip in between"""
+        _check(self.lib.ptx_render_strided(self.h, iter_first, count, stride), "ptx_render_strided")
+        self.iteration = iter_first + (count - 1) * stride
+
+    def write_image(self, rgb_sum):
+        """uploads an accumulation buffer (what read_image returned earlier): resume from a checkpoint"""
+        buf = np.ascontiguousarray(rgb_sum, np.float32).reshape(-1)
+        if buf.size != self.width * self.height * 3:
+            raise PathTracerError("write_image: expected %d floats, got %d" % (self.width * self.height * 3, buf.size))
+        _check(self.lib.ptx_write_image(self.h, _ptr(buf)), "ptx_write_image")
+
+    CKPT_MAGIC = b"PTXCKPT1"
+
+    def save_checkpoint(self, path, iterations_done):
+        """accumulation buffer + the number of iterations in it; same file format as mi355x_pathtrace --checkpoint
+        (csrc/pt_image.h: magic, int32 W, H, int64 iterations, W*H*3 float32)"""
+        img = self.read_image()
+        with open(path, "wb") as f:
+            f.write(self.CKPT_MAGIC)
+            f.write(np.int32([self.width, self.height]).tobytes())
+            f.write(np.int64([iterations_done]).tobytes())
+            f.write(np.ascontiguousarray(img, "<f4").tobytes())
+
+    def load_checkpoint(self, path):
+        """-> iterations already in the buffer; continue with render(iterations + 1, ...)"""
+        with open(path, "rb") as f:
+            if f.read(8) != self.CKPT_MAGIC:
+                raise PathTracerError("%s is not a checkpoint file" % path)
+            w, h = (int(v) for v in np.frombuffer(f.read(8), "<i4"))
+            iters = int(np.frombuffer(f.read(8), "<i8")[0])
+            if (w, h) != (self.width, self.height):
+                raise PathTracerError("checkpoint %s is %dx%d, the tracer is %dx%d" % (path, w, h, self.width, self.height))
+            data = np.frombuffer(f.read(), "<f4")
+        if data.size != w * h * 3:
+            raise PathTracerError("checkpoint %s is truncated" % path)
+        self.write_image(data)
+        return iters
 
     def synchronize(self):
         _check(self.lib.ptx_synchronize(self.h), "ptx_synchronize")

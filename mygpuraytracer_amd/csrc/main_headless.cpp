@@ -5,6 +5,7 @@
 //
 //   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm]
 //                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
+//                                  [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]
 //
 // RES / DEPTH / ITERATIONS overrides and the four switches are what the reference can only change by editing the
 // scene file or the #defines of src/pathtrace.cu:36-40.
@@ -13,6 +14,7 @@
 #include <cstring>
 #include <ctime>
 #include <sstream>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -30,12 +32,13 @@ static std::string currentTimeString() {          // src/preview.cpp:13-19
 int main(int argc, char **argv) {
     const std::string startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]\n", argv[0]);
         return 1;
     }
     int resw = 0, resh = 0, depth = 0, iterations = 0;
     bool pfm = false;
-    std::string out_prefix;
+    std::string out_prefix, ckpt_path, resume_path;
+    int ckpt_every = 0;
     ptx_options &opt = pathtraceOptions();
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -46,6 +49,9 @@ int main(int argc, char **argv) {
         else if (a == "--out") { need(1); out_prefix = argv[++i]; }
         else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
         else if (a == "--pfm") pfm = true;
+        else if (a == "--checkpoint") { need(1); ckpt_path = argv[++i]; }
+        else if (a == "--checkpoint-every") { need(1); ckpt_every = atoi(argv[++i]); }
+        else if (a == "--resume") { need(1); resume_path = argv[++i]; }
         else if (a == "--no-aa") opt.antialiasing = 0;
         else if (a == "--dof") opt.depth_of_field = 1;
         else if (a == "--no-sort") opt.sort_by_material = 0;
@@ -69,15 +75,34 @@ int main(int argc, char **argv) {
     pathtraceInit(scene);
     ptx_tracer *t = pathtraceHandle();
     const int n = (int)scene->state.iterations;
-    if (ptx_render(t, 1, n) != PTX_OK || ptx_read_image(t, &scene->state.image[0].x) != PTX_OK) {
-        fprintf(stderr, "render failed: %s\n", ptx_last_error());
-        return 1;
+    int done = 0;
+    if (!resume_path.empty()) {                 // continue a render: the buffer and the iteration count are all the state
+        long long it = 0;
+        std::string why;
+        if (!ptimg::read_checkpoint(resume_path, width, height, it, &scene->state.image[0].x, why)) { fprintf(stderr, "%s\n", why.c_str()); return 1; }
+        if (ptx_write_image(t, &scene->state.image[0].x) != PTX_OK) { fprintf(stderr, "resume failed: %s\n", ptx_last_error()); return 1; }
+        done = (int)std::min<long long>(it, n);
+        printf("Resumed %s at %d of %d samples.\n", resume_path.c_str(), done, n);
+    }
+    const int rendered = std::max(n - done, 0);
+    const int chunk = (!ckpt_path.empty() && ckpt_every > 0) ? ckpt_every : n;
+    while (done < n) {
+        const int count = std::min(chunk, n - done);
+        if (ptx_render(t, done + 1, count) != PTX_OK || ptx_read_image(t, &scene->state.image[0].x) != PTX_OK) {
+            fprintf(stderr, "render failed: %s\n", ptx_last_error());
+            return 1;
+        }
+        done += count;
+        if (!ckpt_path.empty()) {
+            if (!ptimg::write_checkpoint(ckpt_path, width, height, done, &scene->state.image[0].x)) { fprintf(stderr, "cannot write %s\n", ckpt_path.c_str()); return 1; }
+        }
     }
     ptx_stats st;
     ptx_get_stats(t, &st);
     printf("time: %g\n", st.loop_ms_total);                                             // main.cpp:146
-    printf("%d x %d, depth %d, %d samples: %.3f ms/iteration, %.1f Mrays/s\n", width, height, scene->state.traceDepth, n,
-           st.loop_ms_total / n, st.rays_total / (st.loop_ms_total * 1e-3) / 1e6);
+    if (rendered > 0)
+        printf("%d x %d, depth %d, %d samples (%d traced now): %.3f ms/iteration, %.1f Mrays/s\n", width, height, scene->state.traceDepth, n,
+               rendered, st.loop_ms_total / rendered, st.rays_total / (st.loop_ms_total * 1e-3) / 1e6);
 
     std::ostringstream ss;                                                              // saveImage, main.cpp:94-97
     ss << (out_prefix.empty() ? scene->state.imageName : out_prefix) << "." << startTimeString << "." << n << "samp";

@@ -98,6 +98,7 @@ struct BounceParams {
     PathSoA in, stage;
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
+    int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
     if (tid < 8) tcnt[tid] = 0;
     __syncthreads();
     const int seg = blockIdx.y;
-    const int iter = p.iter + seg;
+    const int iter = p.iter + seg * p.iter_stride;
     const PathSoA in = soa_offset(p.in, p.seg_in * seg), stage = soa_offset(p.stage, p.seg_stage * seg);
     int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
     int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
@@ -887,10 +888,10 @@ int free_tracer(ptx_tracer *t) {
     return PTX_OK;
 }
 
-// Enqueues K consecutive iterations (iter_first .. iter_first+K-1) as K segments of every launch: blockIdx.y picks
+// Enqueues K iterations (iter_first, iter_first + stride, ...) as K segments of every launch: blockIdx.y picks
 // the segment, each segment is an independent stream with its own buffers, so the launches carry K times the work
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
-int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
+int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1) {
     const int nb = t->nbins;
     const int triWords = t->tri_lds ? ((t->ntri_lds * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
@@ -950,7 +951,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K) {
         bp.in = from_cache ? t->soa[2] : t->soa[0];
         bp.stage = t->soa[1];
         bp.image = t->d_image;
-        bp.iter = iter_first; bp.traceDepth = t->traceDepth; bp.bounce = b;
+        bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
         bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.totals_prev = first ? nullptr : totals(b - 1, 1);
@@ -1262,8 +1263,11 @@ int ptx_reset_image(ptx_tracer *t) {
     return PTX_OK;
 }
 
-int ptx_render(ptx_tracer *t, int iter_first, int count) {
+int ptx_render(ptx_tracer *t, int iter_first, int count) { return ptx_render_strided(t, iter_first, count, 1); }
+
+int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    if (stride < 1) return set_error(PTX_ERR_INVALID, "ptx_render_strided: stride must be >= 1");
     if (count <= 0) return PTX_OK;
     HIPCHECK(hipSetDevice(t->device));
     if (t->timing_valid) {          // fold the previous batch's time into the running total before reusing events
@@ -1277,8 +1281,8 @@ int ptx_render(ptx_tracer *t, int iter_first, int count) {
     for (int k = 0; k < count;) {
         int K = std::min(t->kmax, count - k);
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
-        if (t->cache_active() && (!t->cache_valid || iter_first + k == 1)) K = 1;
-        int rc = enqueue_batch(t, iter_first + k, K);
+        if (t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1)) K = 1;
+        int rc = enqueue_batch(t, iter_first + k * stride, K, stride);
         if (rc != PTX_OK) return rc;
         k += K;
     }
@@ -1300,6 +1304,15 @@ int ptx_read_image(ptx_tracer *t, float *host_rgb) {
     if (!t || !host_rgb) return set_error(PTX_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipMemcpyAsync(host_rgb, t->d_image, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, hipMemcpyDeviceToHost, t->stream));
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    return PTX_OK;
+}
+
+// the accumulation buffer back from a checkpoint (W*H*3 floats, the layout ptx_read_image returns)
+int ptx_write_image(ptx_tracer *t, const float *host_rgb) {
+    if (!t || !host_rgb) return set_error(PTX_ERR_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(t->device));
+    HIPCHECK(hipMemcpyAsync(t->d_image, host_rgb, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, hipMemcpyHostToDevice, t->stream));
     HIPCHECK(hipStreamSynchronize(t->stream));
     return PTX_OK;
 }

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <cstring>
 #include <vector>
 
 namespace ptimg {
@@ -89,6 +90,37 @@ inline bool write_pfm(const std::string &path, int w, int h, const float *sum_rg
     }
     fclose(f);
     return true;
+}
+
+// Checkpoint of a render in progress: the accumulation buffer (sum over iterations, as ptx_read_image returns it) and
+// how many iterations are in it.  "PTXCKPT1", int32 W, int32 H, int64 iterations, W*H*3 float32 (little endian).
+// Resuming with ptx_write_image + ptx_render(iterations + 1, ...) continues bit-identically: nothing else carries over
+// between iterations (the RNG is seeded from the iteration number, src/pathtrace.cu:62-66).
+inline bool write_checkpoint(const std::string &path, int w, int h, long long iterations, const float *sum_rgb) {
+    const std::string tmp = path + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const int32_t wh[2] = {w, h};
+    const int64_t it = iterations;
+    bool ok = fwrite("PTXCKPT1", 1, 8, f) == 8 && fwrite(wh, 4, 2, f) == 2 && fwrite(&it, 8, 1, f) == 1 &&
+              fwrite(sum_rgb, sizeof(float), (size_t)w * h * 3, f) == (size_t)w * h * 3;
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;      // never leaves a half-written checkpoint under `path`
+    return ok;
+}
+inline bool read_checkpoint(const std::string &path, int w, int h, long long &iterations, float *sum_rgb, std::string &why) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { why = "cannot open " + path; return false; }
+    char magic[8];
+    int32_t wh[2];
+    int64_t it = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "PTXCKPT1", 8) == 0 && fread(wh, 4, 2, f) == 2 && fread(&it, 8, 1, f) == 1;
+    if (!ok) why = path + " is not a checkpoint file";
+    else if (wh[0] != w || wh[1] != h) { ok = false; why = path + " has another resolution"; }
+    else if (fread(sum_rgb, sizeof(float), (size_t)w * h * 3, f) != (size_t)w * h * 3) { ok = false; why = path + " is truncated"; }
+    fclose(f);
+    iterations = it;
+    return ok;
 }
 
 }  // namespace ptimg

@@ -6,6 +6,11 @@ interleaving balances it), accumulating into a full-frame fp32 buffer in which r
 ``reduce(SUM)`` of that buffer to rank 0 per batch of iterations assembles the frame.  There is no collective on the
 data path itself -- tiles are independent streams.
 
+A second mode shards ITERATIONS instead of pixels (SURVEY 8(e) "next", item 1): rank r traces iterations r+1, r+1+N,
+... of the full frame.  Every iteration then sees exactly the streams the single-GPU run sees, so the summed frame
+equals the single-GPU frame up to the order of the fp32 additions -- which pixel tiles cannot offer, because the
+shading RNG is seeded by a path's position in the sorted stream.  Same single reduce at the end.
+
 The renderer is injected so that the same driver runs on GPUs (``hip_tile_renderer``: the HIP tracer writing straight
 into the torch tensor that RCCL reduces) and, in the CPU tests, over gloo with a stand-in renderer.
 """
@@ -36,6 +41,39 @@ def render_distributed(renderer, width, height, iter_first, count, device, reduc
         if dist.get_rank() != reduce_to:
             image = None
     return image, rays
+
+
+def iteration_share(iter_first, count, rank, world):
+    """(first, n): the iterations first, first + world, ... (n of them) that `rank` takes out of
+    iter_first .. iter_first + count - 1 when the ranks take turns."""
+    n = (count - rank + world - 1) // world if count > rank else 0
+    return iter_first + rank, n
+
+
+def hip_iteration_renderer(scene, rank, world, **opt_kw):
+    """Renderer for render_distributed that shards iterations: full frame on every rank, every world-th iteration."""
+    from . import api
+
+    state = {}
+
+    def renderer(image, iter_first, count):
+        if "tracer" not in state or state["ptr"] != image.data_ptr():
+            if "tracer" in state:
+                state["tracer"].close()
+            kw = dict(opt_kw)
+            kw.setdefault("device", image.device.index if image.device.index is not None else 0)
+            state["tracer"] = api.Tracer(scene, external_image_ptr=image.data_ptr(), **kw)
+            state["ptr"] = image.data_ptr()
+        t = state["tracer"]
+        before = t.stats()["rays_total"]
+        first, n = iteration_share(iter_first, count, rank, world)
+        if n:
+            t.render(first, n, stride=world)
+        t.synchronize()
+        return t.stats()["rays_total"] - before
+
+    renderer.state = state
+    return renderer
 
 
 def hip_tile_renderer(scene, rank, world, tile_rows=TILE_ROWS, **opt_kw):

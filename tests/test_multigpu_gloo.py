@@ -98,3 +98,74 @@ def test_owned_rows_rule():
     # balance at the bench geometry: 1080 rows, 16-row blocks, 8 ranks -> 128..144 rows each
     sizes = [len(multigpu.owned_rows(1080, 16, r, 8)) for r in range(8)]
     assert max(sizes) - min(sizes) <= 16
+
+
+# ---- iteration sharding: rank r traces iterations r+1, r+1+N, ... of the full frame ---------------------------------
+ITERS_TURNS = 5
+
+
+def _oracle_iterations(iters):
+    """sum of the given iterations of the full frame, each traced alone (image reset in between) -> (sum, rays)"""
+    sys.path.insert(0, HERE)
+    from cpulibs import OracleLib
+    O = OracleLib()
+    O.set_libm(1)
+    O.create(_scene_dump(O)); O.apply_runcuda_camera()
+    O.pt_init()
+    rays = 0
+    for it in iters:
+        O.iterate(it)
+        rays += int(O.live_counts().sum())
+    return O.image().reshape(-1).copy(), rays
+
+
+def _worker_turns(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mygpuraytracer_amd import multigpu
+
+    def renderer(image, iter_first, count):
+        first, n = multigpu.iteration_share(iter_first, count, rank, world)
+        img, rays = _oracle_iterations([first + k * world for k in range(n)])
+        image += torch.from_numpy(img)
+        return rays
+
+    image, rays = multigpu.render_distributed(renderer, RES[0], RES[1], 1, ITERS_TURNS, torch.device("cpu"))
+    q.put((rank, None if image is None else image.numpy().copy(), rays))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_taking_turns_reproduce_the_single_run():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_turns, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, img, rays = q.get(timeout=180)
+        got[rank] = (img, rays)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, single_rays = _oracle_iterations(range(1, ITERS_TURNS + 1))
+    odd, _ = _oracle_iterations([1, 3, 5])
+    even, _ = _oracle_iterations([2, 4])
+    assert np.array_equal(got[0][0], odd + even)                      # exactly the two partial sums, added once
+    assert got[0][1] == got[1][1] == single_rays                      # the same streams were traced, ray for ray
+    # against the single run only the order of the fp32 additions differs
+    assert np.allclose(got[0][0], single, rtol=ITERS_TURNS * 2.0 ** -23, atol=0)
+
+
+def test_iteration_share_rule():
+    from mygpuraytracer_amd import multigpu
+    for first, count, world in ((1, 200, 8), (21, 7, 8), (1, 1, 2), (5, 16, 3)):
+        seen = []
+        for r in range(world):
+            f, n = multigpu.iteration_share(first, count, r, world)
+            seen += [f + k * world for k in range(n)]
+        assert sorted(seen) == list(range(first, first + count))
