@@ -133,6 +133,18 @@ void ptx_scene_set_resolution(ptx_scene *s, int w, int h);   /* re-derives fov/p
 const char *ptx_scene_image_name(const ptx_scene *s);  /* RenderState.imageName            */
 void ptx_scene_apply_runcuda_camera(ptx_scene *s);     /* src/main.cpp:56-70 + :105-123    */
 
+/* The interactive camera of src/main.cpp without the window: the state its mouse handlers keep (main.cpp:18-20) and
+ * one function per handler, so that a script of events moves the camera exactly as the same drags would.
+ * After any of them call ptx_orbit_apply (runCuda's recompute) and hand the camera to the tracer with ptx_set_camera +
+ * ptx_reset_image (runCuda restarts the accumulation: iteration = 0, :106). */
+typedef struct ptx_orbit { float phi, theta, zoom; float og_look_at[3]; } ptx_orbit;
+void ptx_orbit_init(const ptx_scene *s, ptx_orbit *o);                                  /* main.cpp:56-70   */
+void ptx_orbit_left_drag(ptx_orbit *o, double dx, double dy, int width, int height);    /* main.cpp:184-189 */
+void ptx_orbit_right_drag(ptx_orbit *o, double dy, int height);                         /* main.cpp:190-194 */
+void ptx_orbit_middle_drag(ptx_scene *s, double dx, double dy);                         /* main.cpp:195-209 */
+void ptx_orbit_recenter(ptx_scene *s, const ptx_orbit *o);                              /* SPACE, :166-171  */
+void ptx_orbit_apply(ptx_scene *s, const ptx_orbit *o);                                 /* main.cpp:105-123 */
+
 /* ---- tracer ------------------------------------------------------------------------------------------------ */
 /* pathtraceInit.  external_image: optional device buffer of W*H*3 floats to accumulate into (caller keeps
  * ownership, e.g. a torch tensor that is later reduced over RCCL); NULL = the tracer allocates and zeroes one.

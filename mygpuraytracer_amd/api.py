@@ -78,6 +78,11 @@ def build_library(force=False):
 _lib = None
 
 
+class Orbit(C.Structure):
+    """ptx_orbit: phi, theta, zoom and the original lookAt of src/main.cpp:18-20"""
+    _fields_ = [("phi", C.c_float), ("theta", C.c_float), ("zoom", C.c_float), ("og_look_at", C.c_float * 3)]
+
+
 def load_library():
     """Loads the native library; raises loudly when it has not been built -- there is no fallback."""
     global _lib
@@ -104,6 +109,12 @@ def load_library():
     L.ptx_scene_set_resolution.argtypes = [vp, i, i]
     L.ptx_scene_image_name.restype, L.ptx_scene_image_name.argtypes = C.c_char_p, [vp]
     L.ptx_scene_apply_runcuda_camera.argtypes = [vp]
+    L.ptx_orbit_init.argtypes = [vp, C.POINTER(Orbit)]
+    L.ptx_orbit_left_drag.argtypes = [C.POINTER(Orbit), C.c_double, C.c_double, i, i]
+    L.ptx_orbit_right_drag.argtypes = [C.POINTER(Orbit), C.c_double, i]
+    L.ptx_orbit_middle_drag.argtypes = [vp, C.c_double, C.c_double]
+    L.ptx_orbit_recenter.argtypes = [vp, C.POINTER(Orbit)]
+    L.ptx_orbit_apply.argtypes = [vp, C.POINTER(Orbit)]
     L.ptx_create.restype = i
     L.ptx_create.argtypes = [i, C.POINTER(Geom), i, C.POINTER(Material), C.POINTER(Camera), i, C.POINTER(Options), vp,
                              vp, C.POINTER(vp)]
@@ -233,6 +244,35 @@ class Scene:
 
     def apply_runcuda_camera(self):
         self.lib.ptx_scene_apply_runcuda_camera(self.h)
+
+    # --- the interactive camera of src/main.cpp, driven by a script instead of a mouse ---------------------
+    def orbit_init(self):
+        """main.cpp:56-70 -> Orbit (phi, theta, zoom, original lookAt)"""
+        o = Orbit()
+        self.lib.ptx_orbit_init(self.h, C.byref(o))
+        return o
+
+    def orbit_events(self, orbit, events):
+        """Applies mouse/key events in order, then runCuda's camera recompute (main.cpp:105-123).  events: tuples
+        ("left", dx, dy) | ("right", dy) | ("middle", dx, dy) | ("space",) with deltas in window pixels, as the GLFW
+        callbacks of main.cpp:166-212 see them.  Hand the result to a tracer with Tracer.set_camera + reset_image."""
+        w, h = self.resolution
+        for ev in events:
+            kind = ev[0]
+            if kind == "left":
+                self.lib.ptx_orbit_left_drag(C.byref(orbit), float(ev[1]), float(ev[2]), w, h)
+            elif kind == "right":
+                self.lib.ptx_orbit_right_drag(C.byref(orbit), float(ev[1]), h)
+            elif kind == "middle":
+                self.lib.ptx_orbit_middle_drag(self.h, float(ev[1]), float(ev[2]))
+            elif kind == "space":
+                self.lib.ptx_orbit_recenter(self.h, C.byref(orbit))
+            else:
+                raise PathTracerError("unknown camera event %r" % (ev,))
+            # main.cpp applies the recompute on the next frame, i.e. between any two events that set camchanged;
+            # the middle drag reads cam.view / cam.right of the recomputed camera, so do the same here
+            self.lib.ptx_orbit_apply(self.h, C.byref(orbit))
+        return orbit
 
     def dump(self):
         """POD view of the scene as numpy arrays (same dict layout the CPU checkers use in tests/cpulibs.py)."""

@@ -6,6 +6,7 @@
 //   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm]
 //                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
 //                                  [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]
+//                                  [--orbit "left:DX,DY;right:DY;middle:DX,DY;space"]   (the mouse of main.cpp:166-212, scripted)
 //
 // RES / DEPTH / ITERATIONS overrides and the four switches are what the reference can only change by editing the
 // scene file or the #defines of src/pathtrace.cu:36-40.
@@ -32,12 +33,12 @@ static std::string currentTimeString() {          // src/preview.cpp:13-19
 int main(int argc, char **argv) {
     const std::string startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT]\n", argv[0]);
         return 1;
     }
     int resw = 0, resh = 0, depth = 0, iterations = 0;
     bool pfm = false;
-    std::string out_prefix, ckpt_path, resume_path;
+    std::string out_prefix, ckpt_path, resume_path, orbit_script;
     int ckpt_every = 0;
     ptx_options &opt = pathtraceOptions();
     for (int i = 2; i < argc; i++) {
@@ -52,6 +53,7 @@ int main(int argc, char **argv) {
         else if (a == "--checkpoint") { need(1); ckpt_path = argv[++i]; }
         else if (a == "--checkpoint-every") { need(1); ckpt_every = atoi(argv[++i]); }
         else if (a == "--resume") { need(1); resume_path = argv[++i]; }
+        else if (a == "--orbit") { need(1); orbit_script = argv[++i]; }
         else if (a == "--no-aa") opt.antialiasing = 0;
         else if (a == "--dof") opt.depth_of_field = 1;
         else if (a == "--no-sort") opt.sort_by_material = 0;
@@ -68,7 +70,8 @@ int main(int argc, char **argv) {
     if (resw > 0 && resh > 0) scene->setResolution(resw, resh);
     if (depth > 0) scene->state.traceDepth = depth;
     if (iterations > 0) scene->state.iterations = (unsigned)iterations;
-    scene->applyRunCudaCamera();
+    if (orbit_script.empty()) scene->applyRunCudaCamera();
+    else if (!scene->runOrbitScript(orbit_script)) { fprintf(stderr, "bad --orbit script: %s\n", orbit_script.c_str()); return 1; }
     const int width = scene->state.camera.resolution[0], height = scene->state.camera.resolution[1];
 
     pathtraceFree();

@@ -42,6 +42,34 @@ void Scene::applyRunCudaCamera() {
     state.camera = *ptx_scene_camera(impl_);
 }
 
+bool Scene::runOrbitScript(const std::string &script) {
+    *ptx_scene_camera(impl_) = state.camera;
+    ptx_orbit o;
+    ptx_orbit_init(impl_, &o);
+    ptx_orbit_apply(impl_, &o);
+    const int w = state.camera.resolution[0], h = state.camera.resolution[1];
+    size_t pos = 0;
+    bool ok = true;
+    while (pos <= script.size() && ok) {
+        size_t end = script.find(';', pos);
+        if (end == std::string::npos) end = script.size();
+        std::string ev = script.substr(pos, end - pos);
+        pos = end + 1;
+        while (!ev.empty() && ev.front() == ' ') ev.erase(ev.begin());
+        while (!ev.empty() && ev.back() == ' ') ev.pop_back();
+        if (ev.empty()) continue;
+        double a = 0.0, b = 0.0;
+        if (ev == "space") ptx_orbit_recenter(impl_, &o);
+        else if (sscanf(ev.c_str(), "left:%lf,%lf", &a, &b) == 2) ptx_orbit_left_drag(&o, a, b, w, h);
+        else if (sscanf(ev.c_str(), "middle:%lf,%lf", &a, &b) == 2) ptx_orbit_middle_drag(impl_, a, b);
+        else if (sscanf(ev.c_str(), "right:%lf", &a) == 1) ptx_orbit_right_drag(&o, a, h);
+        else ok = false;
+        if (ok) ptx_orbit_apply(impl_, &o);
+    }
+    state.camera = *ptx_scene_camera(impl_);
+    return ok;
+}
+
 void Scene::setResolution(int w, int h) {
     ptx_scene_set_resolution(impl_, w, h);
     state.camera = *ptx_scene_camera(impl_);

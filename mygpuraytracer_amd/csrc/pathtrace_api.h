@@ -47,6 +47,9 @@ public:
     RenderState state;
     ptx_scene *handle() const { return impl_; }
     void applyRunCudaCamera();            // src/main.cpp:56-70 + 105-123 (what the first runCuda() call does)
+    // main.cpp's mouse, scripted: "left:DX,DY;right:DY;middle:DX,DY;space" (window pixels).  Starts from the loader's
+    // camera like main() does (:56-70), applies runCuda's recompute (:105-123) first and after every event.
+    bool runOrbitScript(const std::string &script);
     void setResolution(int w, int h);     // harness override of RES (re-derives fov / pixelLength as loadCamera does)
 private:
     ptx_scene *impl_;

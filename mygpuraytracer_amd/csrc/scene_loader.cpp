@@ -411,17 +411,53 @@ void ptx_scene_set_resolution(ptx_scene *s, int w, int h) {
     camera_derive(*s);
 }
 
-// main.cpp:56-70 (phi/theta/zoom from the loader camera) then runCuda's recompute, main.cpp:105-123
-void ptx_scene_apply_runcuda_camera(ptx_scene *s) {
-    if (!s) return;
-    ptx_camera &cam = s->camera;
+// ---- camera controls of src/main.cpp as plain functions (no window: a script of mouse events drives them) ----------
+// main.cpp:56-70: phi (horizontal) and theta (vertical) of the loader's view vector, zoom = |position - lookAt|
+void ptx_orbit_init(const ptx_scene *s, ptx_orbit *o) {
+    if (!s || !o) return;
+    const ptx_camera &cam = s->camera;
     float viewXZ[3] = {cam.view[0], 0.0f, cam.view[2]}, viewZY[3] = {0.0f, cam.view[1], cam.view[2]};
     float nxz[3], nzy[3];
     pth::norm3(viewXZ, nxz); pth::norm3(viewZY, nzy);
-    float phi = acosf(nxz[0] * 0.f + nxz[1] * 0.f + nxz[2] * -1.f);
-    float theta = acosf(nzy[0] * 0.f + nzy[1] * 1.f + nzy[2] * 0.f);
+    o->phi = acosf(nxz[0] * 0.f + nxz[1] * 0.f + nxz[2] * -1.f);
+    o->theta = acosf(nzy[0] * 0.f + nzy[1] * 1.f + nzy[2] * 0.f);
     float d[3] = {cam.position[0] - cam.lookAt[0], cam.position[1] - cam.lookAt[1], cam.position[2] - cam.lookAt[2]};
-    float zoom = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    o->zoom = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    for (int k = 0; k < 3; k++) o->og_look_at[k] = cam.lookAt[k];
+}
+// left button drag, main.cpp:184-189 (xpos - lastX and ypos - lastY are doubles there)
+void ptx_orbit_left_drag(ptx_orbit *o, double dx, double dy, int width, int height) {
+    if (!o) return;
+    o->phi = (float)((double)o->phi - dx / width);
+    o->theta = (float)((double)o->theta - dy / height);
+    o->theta = fmaxf(0.001f, fminf(o->theta, 3.1415926535897932384626422832795028841971f));
+}
+// right button drag, main.cpp:190-194
+void ptx_orbit_right_drag(ptx_orbit *o, double dy, int height) {
+    if (!o) return;
+    o->zoom = (float)((double)o->zoom + dy / height);
+    o->zoom = fmaxf(0.1f, o->zoom);
+}
+// middle button drag, main.cpp:195-209: lookAt slides in the ground plane
+void ptx_orbit_middle_drag(ptx_scene *s, double dx, double dy) {
+    if (!s) return;
+    ptx_camera &cam = s->camera;
+    float f[3] = {cam.view[0], 0.0f, cam.view[2]}, r[3] = {cam.right[0], 0.0f, cam.right[2]}, fn[3], rn[3];
+    pth::norm3(f, fn); pth::norm3(r, rn);
+    const float fx = (float)dx, fy = (float)dy;
+    for (int k = 0; k < 3; k++) cam.lookAt[k] -= fx * rn[k] * 0.01f;
+    for (int k = 0; k < 3; k++) cam.lookAt[k] += fy * fn[k] * 0.01f;
+}
+// SPACE, main.cpp:166-171
+void ptx_orbit_recenter(ptx_scene *s, const ptx_orbit *o) {
+    if (!s || !o) return;
+    for (int k = 0; k < 3; k++) s->camera.lookAt[k] = o->og_look_at[k];
+}
+// runCuda's recompute when camchanged, main.cpp:105-123
+void ptx_orbit_apply(ptx_scene *s, const ptx_orbit *o) {
+    if (!s || !o) return;
+    ptx_camera &cam = s->camera;
+    const float phi = o->phi, theta = o->theta, zoom = o->zoom;
     float cp[3];
     cp[0] = zoom * sinf(phi) * sinf(theta);
     cp[1] = zoom * cosf(theta);
@@ -433,6 +469,14 @@ void ptx_scene_apply_runcuda_camera(ptx_scene *s) {
     pth::cross3(v, u, r);
     pth::cross3(r, v, up);
     for (int k = 0; k < 3; k++) { cam.view[k] = v[k]; cam.up[k] = up[k]; cam.right[k] = r[k]; cam.position[k] = cp[k] + cam.lookAt[k]; }
+}
+
+// what the first runCuda() of a session does: main.cpp:56-70 then :105-123
+void ptx_scene_apply_runcuda_camera(ptx_scene *s) {
+    if (!s) return;
+    ptx_orbit o;
+    ptx_orbit_init(s, &o);
+    ptx_orbit_apply(s, &o);
 }
 
 }  // extern "C"

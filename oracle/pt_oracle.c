@@ -1199,6 +1199,54 @@ void o_camera_from_loader(int resx, int resy, float fovy, const float eye[3], co
     f19[15] = fovx; f19[16] = fovy; f19[17] = plx; f19[18] = ply;
 }
 
+/* ---- camera controls of src/main.cpp as plain functions (the mouse handlers :180-212, SPACE :166-171) -------------
+ * orbit4 = {phi, theta, zoom} of main.cpp:18 and f19 = the camera floats (position 0, lookAt 3, view 6, up 9, right 12).
+ * xpos/ypos deltas are doubles as in the GLFW callbacks; phi, theta and zoom are floats, so each update rounds once. */
+void o_orbit_init(const float f19[19], float orbit3[3], float og_look_at[3]) {            /* main.cpp:56-70 */
+    v3 position = ld3(f19 + 0), lookAt = ld3(f19 + 3), view = ld3(f19 + 6);
+    v3 viewXZ = V3(view.x, 0.0f, view.z);
+    v3 viewZY = V3(0.0f, view.y, view.z);
+    orbit3[0] = acosf(dot3(normalize3(viewXZ), V3(0, 0, -1)));
+    orbit3[1] = acosf(dot3(normalize3(viewZY), V3(0, 1, 0)));
+    orbit3[2] = length3(sub3(position, lookAt));
+    st3(og_look_at, lookAt);
+}
+void o_orbit_left_drag(float orbit3[3], double dx, double dy, int width, int height) {    /* :184-189 */
+    orbit3[0] = (float)((double)orbit3[0] - dx / width);
+    orbit3[1] = (float)((double)orbit3[1] - dy / height);
+    orbit3[1] = fmaxf(0.001f, fminf(orbit3[1], 3.1415926535897932384626422832795028841971f));
+}
+void o_orbit_right_drag(float orbit3[3], double dy, int height) {                          /* :190-194 */
+    orbit3[2] = (float)((double)orbit3[2] + dy / height);
+    orbit3[2] = fmaxf(0.1f, orbit3[2]);
+}
+void o_orbit_middle_drag(float f19[19], double dx, double dy) {                            /* :195-209 */
+    v3 forward = ld3(f19 + 6);
+    forward.y = 0.0f;
+    forward = normalize3(forward);
+    v3 right = ld3(f19 + 12);
+    right.y = 0.0f;
+    right = normalize3(right);
+    v3 lookAt = ld3(f19 + 3);
+    lookAt = sub3(lookAt, scale3(scale3(right, (float)dx), 0.01f));       /* (float)(dx) * right * 0.01f, left to right */
+    lookAt = add3(lookAt, scale3(scale3(forward, (float)dy), 0.01f));
+    st3(f19 + 3, lookAt);
+}
+void o_orbit_apply(float f19[19], const float orbit3[3]) {                                  /* runCuda, :105-123 */
+    const float phi = orbit3[0], theta = orbit3[1], zoom = orbit3[2];
+    v3 lookAt = ld3(f19 + 3);
+    v3 cameraPosition;
+    cameraPosition.x = zoom * sinf(phi) * sinf(theta);
+    cameraPosition.y = zoom * cosf(theta);
+    cameraPosition.z = zoom * cosf(phi) * sinf(theta);
+    v3 v = neg3(normalize3(cameraPosition));
+    v3 u = V3(0, 1, 0);
+    v3 r = cross3(v, u);
+    v3 up = cross3(r, v);
+    cameraPosition = add3(cameraPosition, lookAt);
+    st3(f19 + 0, cameraPosition); st3(f19 + 6, v); st3(f19 + 9, up); st3(f19 + 12, r);
+}
+
 /* main.cpp:56-70 then runCuda's recompute main.cpp:105-123 */
 void o_runcuda_camera(float f19[19]) {
     v3 position = ld3(f19 + 0), lookAt = ld3(f19 + 3), view = ld3(f19 + 6);

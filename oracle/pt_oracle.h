@@ -59,6 +59,12 @@ void o_build_transforms(const float trs9[9], float out48[48]);
 void o_camera_from_loader(int resx, int resy, float fovy, const float eye[3], const float lookat[3],
                           const float up[3], float f19[19]);
 void o_runcuda_camera(float f19[19]);
+/* camera controls of src/main.cpp:56-70,105-123,166-171,180-212 (orbit3 = phi, theta, zoom) */
+void o_orbit_init(const float f19[19], float orbit3[3], float og_look_at[3]);
+void o_orbit_left_drag(float orbit3[3], double dx, double dy, int width, int height);
+void o_orbit_right_drag(float orbit3[3], double dy, int height);
+void o_orbit_middle_drag(float f19[19], double dx, double dy);
+void o_orbit_apply(float f19[19], const float orbit3[3]);
 
 /* scene = POD arrays */
 void *o_scene_create(int ngeoms, const int *gints3, const float *gmats48, int nmat, const float *mats11);

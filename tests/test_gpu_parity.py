@@ -289,6 +289,30 @@ def test_tile_split_matches_oracle_on_the_same_tile(gpu_product, O):
     T.close()
 
 
+def test_scripted_camera_orbit_on_a_live_tracer(gpu_product, O):
+    """runCuda after a mouse drag (src/main.cpp:105-127): new camera, accumulation restarted, no re-init needed here
+    (buffer sizes do not change).  The frame equals the oracle's for the moved camera -- and a cached first bounce from
+    the old camera must not survive the move."""
+    for scene, opt in (("cornellObj.txt", {}), ("cornell.txt", dict(antialiasing=0))):
+        s = gpu_product.Scene(os.path.join(ROOT, "scenes", scene), res=(96, 54), depth=6)
+        orb = s.orbit_init()
+        s.orbit_events(orb, [])
+        with gpu_product.Tracer(s, **opt) as T:
+            T.render(1, 3)
+            s.orbit_events(orb, [("left", 11.0, -4.0), ("right", 20.0), ("middle", 30.0, 10.0)])
+            T.set_camera(s)
+            T.reset_image()
+            T.render(1, 3)
+            d = s.dump()
+            O.set_libm(1)
+            O.create(d, d["textures"])
+            O.set_options(aa=opt.get("antialiasing", 1), dof=0, sort=1, cache=1)
+            O.pt_init()
+            for it in (1, 2, 3):
+                O.iterate(it)
+            assert beq(T.read_image(), O.image())
+
+
 def test_error_paths(gpu_product):
     pt = gpu_product
     s = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(32, 32), depth=0)
@@ -387,6 +411,17 @@ def test_headless_driver(gpu_product, tmp_path):
         T.render(1, 3)
         want = T.read_image().reshape(48, 64, 3) / np.float32(3)
     assert np.array_equal(frame, want)
+    # the same with main.cpp's mouse scripted (--orbit): equals the Python host side driving the same events
+    subprocess.check_call([exe, os.path.join(ROOT, "scenes", "cornellObj.txt"), "--res", "64", "48", "--depth", "5", "--iterations", "2",
+                           "--out", str(tmp_path / "orb"), "--pfm", "--orbit", "left:11,-4; right:20;middle:30,10"])
+    raw = open(glob.glob(str(tmp_path / "orb.*.2samp.pfm"))[0], "rb").read()
+    frame = np.frombuffer(raw[raw.index(b"-1.0\n") + 5:], np.float32).reshape(48, 64, 3)[::-1]
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(64, 48), depth=5)
+    orb = s.orbit_init()
+    s.orbit_events(orb, [("left", 11.0, -4.0), ("right", 20.0), ("middle", 30.0, 10.0)])
+    with gpu_product.Tracer(s) as T:
+        T.render(1, 2)
+        assert np.array_equal(frame, T.read_image().reshape(48, 64, 3) / np.float32(2))
 
 
 @pytest.mark.parametrize("tag,scene,res", [("apps_ship", "cornellSpaceship.txt", (96, 54)), ("apps_glass", "cornellGlass.txt", (64, 64))])
