@@ -65,3 +65,51 @@ def test_random_stage_inputs(ref_lib, oracle_lib):
     assert beq(ri, oi)
     idx = rng.integers(0, 3_000_000, 6000).astype(np.int32)
     assert beq(ref_lib.shade(9, 1, idx, ri, p), oracle_lib.shade(9, 1, idx, oi, p))
+
+
+def _cottage_scene_text(res=(96, 54), depth=6):
+    """the reference's cornellObj.txt with its cube swapped for models/cottage_obj.obj (5 objects, 3 materials, 32
+    triangles + 227 quads = 486 triangles), scaled into the box.  Read where it lies under /root/reference."""
+    text = open(os.path.join(REFERENCE_ROOT, "scenes", "cornellObj.txt")).read()
+    assert "../models/cube.obj" in text
+    text = text.replace("../models/cube.obj", "../models/cottage_obj.obj")
+    head, tail = text.rsplit("TRANS", 1)
+    tail = "       0.5 1.2 0\nROTAT       0 30 0\nSCALE       .02 .02 .02\n"
+    return scene_text_with(head + "TRANS" + tail, res, depth)
+
+
+def test_cottage_mesh_loader_oracle_and_bvh(ref_lib, oracle_lib, product, tmp_path):
+    """A second real mesh, never copied into this repo: the reference loader, this repo's loader, the
+    oracle's frame and the BVH are compared on it in place."""
+    import ctypes as C
+    text = _cottage_scene_text()
+    ref_lib.load_text(text)
+    rd = ref_lib.dump()
+    (tmp_path / "scenes").mkdir()
+    os.symlink(os.path.join(REFERENCE_ROOT, "models"), tmp_path / "models")
+    (tmp_path / "scenes" / "cottage.txt").write_text(text)
+    d = product.Scene(str(tmp_path / "scenes" / "cottage.txt")).dump()
+    for k in ("geom_ints", "geom_trs", "geom_mats", "materials", "cam_floats"):
+        assert beq(d[k], rd[k]), k
+    assert len(d["faces"]) == len(rd["faces"])
+    for a, b in zip(d["faces"], rd["faces"]):
+        assert beq(a, b)
+    mesh = [f for f in d["faces"] if len(f)]
+    assert len(mesh) == 1 and mesh[0].size == 486 * 15
+    # frames: oracle == reference build
+    oracle_lib.set_libm(0)
+    oracle_lib.create(rd)
+    ref_lib.apply_runcuda_camera(); oracle_lib.apply_runcuda_camera()
+    ref_lib.pt_init(); oracle_lib.pt_init()
+    for it in (1, 2):
+        ref_lib.iterate(it); oracle_lib.iterate(it)
+        assert beq(ref_lib.live_counts(), oracle_lib.live_counts())
+    assert beq(ref_lib.image(), oracle_lib.image())
+    # BVH == the loop over its 486 faces, on rays around the object-space mesh
+    from test_bvh import run_check, rays_around
+    rng = np.random.default_rng(5)
+    faces = np.asarray(mesh[0], np.float32).reshape(-1, 15)
+    ext = float(np.abs(faces[:, [0, 1, 2, 5, 6, 7, 10, 11, 12]]).max())
+    rays = np.concatenate([rays_around(rng, 20000, 3 * ext, ext), rays_around(rng, 5000, 0.3 * ext, ext)])
+    fl, tl, fb, tb, st = run_check(product, faces, rays)
+    assert beq(fl, fb) and beq(tl, tb) and (fl >= 0).sum() > 2000
