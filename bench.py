@@ -47,7 +47,24 @@ def cpu_baseline(scene, iters):
         rays += int(O.live_counts().sum())
     dt = time.time() - t0
     sec = O.stage_seconds()
+    # StreamCompaction::CPU (stream_compaction/cpu.cu:20-95) on the per-bounce "still alive" flag arrays
+    # of one iteration, timed alone, next to the library's GPU compaction of the same arrays (host pointers in and out)
+    import numpy as np
+    import mygpuraytracer_amd as pt
+    counts = [int(c) for c in O.live_counts()]
+    SC = pt.StreamCompaction()
+    rng = np.random.default_rng(1)
+    ms = dict(cpu_without_scan=0.0, cpu_with_scan=0.0, gpu_efficient_compact=0.0)
+    for b, n in enumerate(counts):
+        alive = counts[b + 1] if b + 1 < len(counts) else 0
+        flags = np.zeros(n, np.int32)
+        flags[rng.permutation(n)[:alive]] = 1
+        a = SC.cpu_compact_without_scan(flags); ms["cpu_without_scan"] += SC.last_cpu_ms()
+        c = SC.cpu_compact_with_scan(flags); ms["cpu_with_scan"] += SC.last_cpu_ms()
+        g = SC.efficient_compact(flags); ms["gpu_efficient_compact"] += SC.last_gpu_ms()
+        assert len(a) == len(c) == len(g) == alive
     return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
+                stream_compaction_ms_per_iteration=dict(elements=sum(counts), **ms),
                 sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
 

@@ -15,10 +15,11 @@ NAMES = {"k_bounce<false>": "k_bounce", "k_bounce<true>": "k_bounce<first>", "k_
 def main(tag, d_stats, d_fetch, d_write):
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    shutil.copy(glob.glob(os.path.join(d_stats, "*", "*_kernel_stats.csv"))[0], os.path.join(out, "%s_kernel_stats.csv" % tag))
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun_out/ keeps earlier calls' files too
+    shutil.copy(newest(os.path.join(d_stats, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats.csv" % tag))
     acc = {}
     for kind, d in (("fetch", d_fetch), ("write", d_write)):
-        f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+        f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
         shutil.copy(f, os.path.join(out, "%s_pmc_%s_size.csv" % (tag, kind)))
         a = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One profiling pass on the GPU box (run through gpurun): kernel trace + stats of the default bench command, then the two
+# PMC passes (FETCH_SIZE, WRITE_SIZE) in runs of their own, as MI355X_MICROARCH.md prescribes.  Output under gpurun_out/.
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'   then   python tools/collect_profiles.py TAG gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
+set -e
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_stats.err
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_fetch.err
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --steps 8 --warmup 8 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_write.err
+echo "write pass done"
+cd $R && python3 bench.py > gpurun_out/bench_plain.json 2> gpurun_out/bench_plain.err
+tail -1 gpurun_out/bench_plain.json | cut -c1-300
