@@ -98,7 +98,8 @@ typedef struct ptx_options {
                                     lists from conservative world boxes; results are identical either way */
     int32_t no_bvh;              /* 1 = every mesh is searched by the reference's loop over all its faces; 0 = meshes of
                                     24+ faces get a bounding-volume hierarchy (same nearest face, see csrc/pt_bvh.h)      */
-    int32_t reserved[2];
+    int32_t lanes;               /* 0 = two launch sets in flight on two streams (default when batch > 1), 1 = one    */
+    int32_t reserved[1];
 } ptx_options;
 
 typedef struct ptx_stats {

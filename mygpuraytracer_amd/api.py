@@ -60,7 +60,7 @@ class Options(C.Structure):
     _fields_ = [("depth_of_field", C.c_int32), ("cache_first_bounce", C.c_int32), ("sort_by_material", C.c_int32),
                 ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
                 ("tile_rows", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("lanes", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):
