@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
                     help="N > 1: 'tiles' = interleaved pixel-row blocks per rank (what north_star prescribes, the default); "
                     "'iterations' = every rank traces the full frame for every N-th iteration (sums to the single-GPU frame)")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="launch sets in flight (ptx_options.lanes): 0 = library default (2: k_move of one batch of 8 iterations "
+                    "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
+                    "because a kernel's duration is only meaningful when it has the GPU to itself)")
     args = ap.parse_args()
 
     import torch
@@ -122,7 +126,7 @@ def main():
     scene.apply_runcuda_camera()
     W, H = RES
     image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
-    kw = dict(device=dev_index)
+    kw = dict(device=dev_index, lanes=args.lanes)
     by_iter = world > 1 and args.shard == "iterations"
     if world > 1 and not by_iter:
         kw.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
@@ -194,7 +198,9 @@ def main():
                     algorithmic_bytes_per_unit=BYTES_BOUNCE_KERNEL,
                     loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / (HBM_PEAK * world), bytes_per_ray=BYTES_LOOP,
                               loop_ms_per_step=loop_ms / args.steps),
-                    kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()})
+                    kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()},
+                    timing="kernel durations: hipEvents around every launch, one launch set at a time (lanes 1); value, ms_per_step "
+                           "and loop: wall time with %d launch set(s) in flight" % (1 if args.lanes == 1 else 2))
 
     out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",

@@ -51,6 +51,9 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #ifndef PT_TILE
 #define PT_TILE 256
 #endif
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 4     // waves per SIMD k_bounce is compiled for (register budget 512 / this)
+#endif
 constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
@@ -282,7 +285,7 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 template <bool FIRST>
-__global__ __launch_bounds__(TILE, 4) void k_bounce(const BounceParams p) {
+__global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p) {
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

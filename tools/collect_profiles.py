@@ -17,6 +17,9 @@ def main(tag, d_stats, d_fetch, d_write):
     os.makedirs(out, exist_ok=True)
     newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun_out/ keeps earlier calls' files too
     shutil.copy(newest(os.path.join(d_stats, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats.csv" % tag))
+    d_stats2 = d_stats.rstrip("/") + "2"           # the default command (two launch sets in flight), when profiled as well
+    if glob.glob(os.path.join(d_stats2, "*", "*_kernel_stats.csv")):
+        shutil.copy(newest(os.path.join(d_stats2, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats_default_2lanes.csv" % tag))
     acc = {}
     for kind, d in (("fetch", d_fetch), ("write", d_write)):
         f = newest(os.path.join(d, "*", "*_counter_collection.csv"))
@@ -37,7 +40,7 @@ def main(tag, d_stats, d_fetch, d_write):
         detail[k] = dict(launches_sampled=len(f), fetch_size_kib_mean=sum(f) / len(f), write_size_kib_mean=sum(w) / len(w),
                          hbm_read_bytes_per_launch=fb, hbm_write_bytes_per_launch=wb)
     res["_detail"] = detail
-    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --steps 8 --warmup 8 "
+    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 8 --warmup 8 "
                    "--no-cpu-baseline; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
                    "FETCH_SIZE correction (checked in round 1 on k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
                    "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 8 iterations (batch 8).")
