@@ -609,12 +609,28 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
 }
 
 // replay of the cached bounce-0 light hits (first-bounce cache, iterations > 1)
-__global__ void k_replay_emission(const int32_t *count, const int32_t *pix, const float *rgb, float *image) {
+// add != 0: image[pix] += rgb (one iteration at a time); add == 0: store into the per-iteration radiance buffer of each of
+// the nseg segments (batched mode; the buffers were cleared, so bounce-0 misses read as 0)
+__global__ void k_replay_emission(const int32_t *count, const int32_t *pix, const float *rgb, float *dst, size_t seg_stride,
+                                  int nseg, int add) {
     int n = *count;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        float *px = image + (size_t)pix[k] * 3;
-        px[0] += rgb[k * 3 + 0]; px[1] += rgb[k * 3 + 1]; px[2] += rgb[k * 3 + 2];
+        const float r = rgb[k * 3 + 0], g = rgb[k * 3 + 1], b = rgb[k * 3 + 2];
+        if (add) {
+            float *px = dst + (size_t)pix[k] * 3;
+            px[0] += r; px[1] += g; px[2] += b;
+        } else {
+            for (int sg = 0; sg < nseg; sg++) {
+                float *px = dst + seg_stride * sg + (size_t)pix[k] * 3;
+                px[0] = r; px[1] = g; px[2] = b;
+            }
+        }
     }
+}
+
+// the cached bounce-0 totals into the totals block of every segment of a batch
+__global__ void k_seed_totals(int32_t *dst, size_t seg_totals, int nseg, const int32_t *src, int n) {
+    for (int k = threadIdx.x; k < n * nseg; k += blockDim.x) dst[seg_totals * (k / n) + (k % n)] = src[k % n];
 }
 
 // batched mode: image[pix] += part[0][pix]; += part[1][pix]; ... in iteration order, over the pixels this device owns
@@ -963,9 +979,16 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         if (first && use_cache) {
             // first-bounce cache: the sorted bounce-0 stream and its light hits are identical every iteration
             // when primary rays are not jittered, so bounce 0 is skipped (intent of src/pathtrace.cu:492-499,514)
-            HIPCHECK(hipMemcpyAsync(totals(0, 0), t->d_cache_totals, sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, stream));
-            hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->d_emit_count, t->d_emit_pix,
-                               t->d_emit_rgb, t->d_image);
+            hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(256), 0, stream, totals(0, 0), seg_totals, K, t->d_cache_totals, 2 * nb);
+            if (batched) {
+                const size_t seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
+                HIPCHECK(hipMemsetAsync(t->d_part + seg0 * seg_part, 0, sizeof(float) * seg_part * (size_t)K, stream));
+                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
+                                   t->d_part + seg0 * seg_part, seg_part, K, 0);
+            } else {
+                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
+                                   t->d_image, (size_t)0, 1, 1);
+            }
             continue;
         }
         BounceParams bp;
@@ -1220,11 +1243,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         t->own_image = true;
     }
     // iterations per launch set: explicit option, or 8 (fewer for frames so large that 8 streams would not fit in
-    // ~16 GB); the first-bounce cache shares one cached stream between iterations and stays unbatched
+    // ~16 GB).  With the first-bounce cache the iterations of a batch all start from the one cached bounce-0 stream
     int kmax = opt.batch;
     if (kmax <= 0) kmax = (int)std::min<long long>(8, std::max<long long>(1, (16LL << 30) / (200LL * std::max(t->tm.owned, 1))));
     if (kmax > 64) kmax = 64;
-    if (t->cache_active()) kmax = 1;
     t->kmax = kmax;
     // two launch sets in flight (one per stream) unless switched off: k_move of one overlaps k_bounce of the other and
     // kernel tails are filled (C4: 0.47 -> 0.37 ms per iteration); needs the per-iteration radiance buffers (kmax > 1)
@@ -1330,8 +1352,13 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
         if (t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1)) K = 1;
         const int lane = nl > 1 ? (batch & 1) : 0;
+        const bool fills = t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1);
         int rc = enqueue_batch(t, iter_first + k * stride, K, stride, lane, nl > 1 && batch > 0);
         if (rc != PTX_OK) return rc;
+        if (fills && nl > 1 && lane == 0) {              // the other lane must not read the cache before it is written
+            HIPCHECK(hipEventRecord(t->ev_fork, t->stream));
+            HIPCHECK(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+        }
         used2 |= lane == 1;
         k += K;
     }

@@ -350,6 +350,25 @@ def test_batched_iterations_identical(gpu_product, batch, tile):
         assert np.array_equal(A.read_image().view(np.uint32), B.read_image().view(np.uint32))
 
 
+@pytest.mark.parametrize("scene,opt", [("cornell.txt", dict(antialiasing=0)), ("cornellObj.txt", {}), ("cornellObj.txt", dict(antialiasing=0, apps_variant=1))])
+def test_two_launch_sets_in_flight_identical(gpu_product, scene, opt):
+    """Default tracer (batches of 8 iterations alternating between two streams, gathers chained in iteration order;
+    with AA off also the batched first-bounce cache: every iteration of a batch starts from the one cached bounce-0
+    stream) against one iteration at a time on one stream: same image bits, same ray totals, over several calls."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(200, 120), depth=7)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, batch=1, lanes=1, **opt) as A, pt.Tracer(s, **opt) as B, pt.Tracer(s, lanes=1, **opt) as C:
+        for first, count in ((1, 37), (38, 5), (43, 20)):
+            A.render(first, count); B.render(first, count); C.render(first, count)
+            a = A.read_image()
+            assert beq(a, B.read_image()) and beq(a, C.read_image())
+            assert A.stats()["rays_total"] == B.stats()["rays_total"] == C.stats()["rays_total"]
+        B.reset_image(); A.reset_image()
+        A.render(5, 19); B.render(5, 19)                               # cache refilled by an iteration other than 1
+        assert beq(A.read_image(), B.read_image())
+
+
 def test_strided_render_and_checkpoint_resume(gpu_product, tmp_path):
     """ptx_render_strided traces exactly the iterations it names (each equal to that iteration traced alone), with and
     without batching; a checkpoint written mid-way and resumed in a fresh tracer ends bit-identical to the straight run."""

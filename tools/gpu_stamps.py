@@ -5,8 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import mygpuraytracer_amd as pt
-s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(1920, 1080), depth=8); s.apply_runcuda_camera()
-T = pt.Tracer(s)
+scene = sys.argv[1] if len(sys.argv) > 1 else "cornellObj.txt"
+res = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import ensure_standin_assets
+ensure_standin_assets()
+s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=8); s.apply_runcuda_camera()
+T = pt.Tracer(s, depth_of_field=1 if "Spaceship" in scene else 0, lanes=1)
 L = pt.load_library()
 L.ptx_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 out = np.zeros(32, np.uint64)
