@@ -99,7 +99,8 @@ typedef struct ptx_options {
     int32_t no_bvh;              /* 1 = every mesh is searched by the reference's loop over all its faces; 0 = meshes of
                                     24+ faces get a bounding-volume hierarchy (same nearest face, see csrc/pt_bvh.h)      */
     int32_t lanes;               /* 0 = two launch sets in flight on two streams (default when batch > 1), 1 = one    */
-    int32_t reserved[1];
+    int32_t no_mesh_split;       /* 1 = meshes are searched inside the bounce kernel even when they have a BVH; 0 = scenes
+                                    with BVH meshes run the mesh search as a kernel of its own between two halves of it   */
 } ptx_options;
 
 typedef struct ptx_stats {
@@ -184,7 +185,7 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out);
 int ptx_owned_pixels(const ptx_tracer *t);              /* pixels this tracer generates (tile split)        */
 void *ptx_stream(ptx_tracer *t);
 /* Optional per-kernel device timing (hipEvents on the tracer's stream around every launch while on).
- * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = unused, 3 = k_move.
+ * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh (split mesh search only), 3 = k_move.
  * ptx_get_kernel_times returns the sums since it was last called and clears them. */
 int ptx_set_kernel_timing(ptx_tracer *t, int on);
 int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_by_kind[4]);

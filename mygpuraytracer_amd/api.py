@@ -60,7 +60,7 @@ class Options(C.Structure):
     _fields_ = [("depth_of_field", C.c_int32), ("cache_first_bounce", C.c_int32), ("sort_by_material", C.c_int32),
                 ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
                 ("tile_rows", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("lanes", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("lanes", C.c_int32), ("no_mesh_split", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -431,7 +431,7 @@ class Tracer:
         ms = np.zeros(4, np.float64)
         n = np.zeros(4, np.int64)
         _check(self.lib.ptx_get_kernel_times(self.h, _ptr(ms), _ptr(n)), "ptx_get_kernel_times")
-        names = ("k_bounce<first>", "k_bounce", "unused", "k_move")
+        names = ("k_bounce<first>", "k_bounce", "k_mesh", "k_move")
         return {nm: (float(ms[k]), int(n[k])) for k, nm in enumerate(names)}
 
     def owned_pixels(self):

@@ -102,6 +102,9 @@ struct BounceParams {
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
+    // split mesh search (MODE 1 / 2 of k_bounce, k_mesh in between): per-ray keys, the queue of (ray, mesh) pairs
+    unsigned long long *keys; uint32_t *items; int32_t *item_count;
+    size_t seg_keys, seg_items;            // per-segment strides of keys / items; item_count has one int per segment
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
@@ -190,8 +193,12 @@ constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contri
 #define TI_ARGS
 #define TI_PASS
 #endif
+// DEFER: the mesh pairs are not worked off here; the caller gets the best key over cubes and spheres and the ray's
+// mesh candidates (split mesh search, see k_mesh), and `hit` is left alone.
+template <bool DEFER>
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
-                                              int32_t *tcnt, int &q, int tid, int lane, int wave TI_ARGS) {
+                                              int32_t *tcnt, int &q, int tid, int lane, int wave, unsigned long long &key_out,
+                                              uint32_t &mesh_out TI_ARGS) {
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
@@ -203,6 +210,8 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
         const uint32_t m = cullMask(sc, ray);
         cube_mask = m & sc.cube_bits; sph_mask = m & sc.sphere_bits; mesh_mask = m & sc.mesh_bits;
     }
+    mesh_out = mesh_mask;
+    if (DEFER) mesh_mask = 0;
     rayb[0 * TILE + tid] = ray.o.x; rayb[1 * TILE + tid] = ray.o.y; rayb[2 * TILE + tid] = ray.o.z;
     rayb[3 * TILE + tid] = ray.d.x; rayb[4 * TILE + tid] = ray.d.y; rayb[5 * TILE + tid] = ray.d.z;
     best[tid] = KEY_NONE;
@@ -279,12 +288,34 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
         if (!more) break;
     }
     // no barrier here: the caller passes at least two before it touches `scratch` again
-    decodeKey(sc, gtab, best[tid], ray, need_uv, hit);
+    key_out = best[tid];
+    if (!DEFER) decodeKey(sc, gtab, key_out, ray, need_uv, hit);
     TI_STAMP(7);
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
-template <bool FIRST>
+constexpr int SPLIT_MAX_MESHES = 2;                  // meshes per scene the split mesh search handles (2 bits of count per ray)
+constexpr int QCAP = 4 * TILE;                       // LDS queue entries (fits rec[12*TILE .. 17*TILE) with its two counters)
+static_assert(12 * TILE + QCAP + 2 <= 17 * TILE, "LDS queue must fit the record buffer");
+// MODE 1: LDS queue -> global queue of the segment (all threads of the workgroup; uniform call)
+__device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const uint32_t *qbuf, int32_t *qcnt, int32_t *qbase, int tid) {
+    const int n = *qcnt;
+    if (tid == 0) *qbase = atomicAdd(p.item_count + seg, n);
+    __syncthreads();
+    uint32_t *dst = p.items + p.seg_items * seg + *qbase;
+    for (int k = tid; k < n; k += TILE) dst[k] = qbuf[k];
+    __syncthreads();
+    if (tid == 0) *qcnt = 0;
+    __syncthreads();
+}
+
+// MODE 0: the whole bounce.  Scenes with BVH meshes split it so that the mesh search -- few rays of a tile, each a long
+// chain of dependent node visits -- does not hold the tile's other waves at a barrier: MODE 1 does everything up to the
+// best hit among cubes and spheres and parks the ray (origin, direction, colour, pixel in the stage arrays of its own
+// tile slot, the key in `keys`) plus one queue entry per (ray, mesh) candidate; k_mesh walks the queue with one lane
+// per entry in dense, lean waves and folds its keys in with 64-bit atomic minima; MODE 2 picks the rays up again and
+// does the rest (winner's normal, terminal cases, ranking, in-tile sort, stage write).  Same arithmetic, same bits.
+template <bool FIRST, int MODE>
 __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p) {
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
@@ -299,6 +330,9 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + 12 * TILE);   // MODE 1: LDS stage of the (ray, mesh) queue, [QCAP]
+    int32_t *qcnt = rec + 12 * TILE + QCAP, *qbase = qcnt + 1;
+    if (MODE == 1 && tid == 0) *qcnt = 0;
     if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
     if (tid < 8) tcnt[tid] = 0;
@@ -333,7 +367,18 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         int pix = 0;
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
-        if (alive) {
+        unsigned long long key = KEY_NONE;
+        if (MODE == 2) {                 // parked by MODE 1 in this tile's stage slots
+            alive = false;
+            if (i < n_in) {
+                pix = stage.pix[i];
+                alive = pix >= 0;
+                ps.o = V3(stage.px[i], stage.py[i], stage.pz[i]);
+                ps.d = V3(stage.dx[i], stage.dy[i], stage.dz[i]);
+                ps.color = V3(stage.cr[i], stage.cg[i], stage.cb[i]);
+                key = (p.keys + p.seg_keys * seg)[i];
+            }
+        } else if (alive) {
             if (FIRST) {
                 int x, y;
                 owned_pixel(p.tm, i, x, y);
@@ -373,7 +418,41 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
         {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
-            if (p.sc.cull) tileIntersect(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave TI_PASS);
+            uint32_t mesh_cand = 0;
+            if (MODE == 1) {
+                tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
+                // park the ray and queue its mesh candidates: per mesh present in the wave one atomic for the base
+                if (i < n_in) {
+                    stage.px[i] = ray.o.x; stage.py[i] = ray.o.y; stage.pz[i] = ray.o.z;
+                    stage.dx[i] = ray.d.x; stage.dy[i] = ray.d.y; stage.dz[i] = ray.d.z;
+                    stage.cr[i] = ps.color.x; stage.cg[i] = ps.color.y; stage.cb[i] = ps.color.z;
+                    stage.pix[i] = alive ? pix : -1;
+                    (p.keys + p.seg_keys * seg)[i] = key;
+                }
+                // queue entries go through an LDS buffer (the upper part of `rec`, free in this mode) and reach the global
+                // queue in blocks: one global atomic per ~30 tiles instead of one per wave (a single hot counter)
+                {
+                    const int mine = (int)__popc(mesh_cand);                     // 0 .. SPLIT_MAX_MESHES
+                    const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2);
+                    const int wtot = __popcll(b0) + 2 * __popcll(b1);
+                    int base = 0;
+                    if (lane == 0 && wtot) base = atomicAdd(qcnt, wtot);
+                    base = __builtin_amdgcn_readfirstlane(base) + wavePrefix(b0, lane) + 2 * wavePrefix(b1, lane);
+                    uint32_t m = mesh_cand;
+                    for (int j = 0; j < mine; j++) {
+                        const int g = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        qbuf[base + j] = (uint32_t)i | ((uint32_t)g << 26);
+                    }
+                }
+                __syncthreads();
+                if (*qcnt > QCAP - TILE * SPLIT_MAX_MESHES) flushQueue(p, seg, qbuf, qcnt, qbase, tid);
+                continue;                // (the barrier above also frees scratch and histogram for the next tile)
+            } else if (MODE == 2) {
+                if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
+                                     p.uses_uv != 0, hit);
+                __syncthreads();                                  // histogram zeroed
+            } else if (p.sc.cull) tileIntersect<false>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
             else {
                 if (alive) intersectScene(p.sc, ray, hit);
                 __syncthreads();                                  // histogram zeroed (tileIntersect has barriers of its own)
@@ -514,12 +593,42 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     if (lane == 0 && p.stamps)
         for (int k = 0; k < 12; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
 #endif
+    if (MODE == 1) {                     // counts belong to MODE 2; what is left in the LDS queue goes out now
+        if (*qcnt > 0) flushQueue(p, seg, qbuf, qcnt, qbase, tid);
+        return;
+    }
     for (int b = tid; b < nb; b += TILE) {
         const int ca = run_all[b], cs = run_scat[b];
         chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
         chunk_scat[(size_t)b * gridDim.x + blockIdx.x] = cs;
         if (ca) { atomicAdd(&super_all[b * p.nsuper + (blockIdx.x >> 6)], ca); atomicAdd(&totals_all[b], ca); }
         if (cs) { atomicAdd(&super_scat[b * p.nsuper + (blockIdx.x >> 6)], cs); atomicAdd(&totals_scat[b], cs); }
+    }
+}
+
+// Split mesh search, middle part: one lane per queued (ray, mesh) pair.  The ray is read from where MODE 1 parked it,
+// the mesh is searched (BVH or the plain loop, tables in global memory) and the result folded into the ray's key with a
+// 64-bit atomic minimum -- the same key and the same minimum as in tileIntersect, so the same winner.
+struct MeshParams {
+    DScene sc;
+    PathSoA stage;
+    unsigned long long *keys; const uint32_t *items; const int32_t *item_count;
+    size_t seg_stage, seg_keys, seg_items;
+};
+__global__ __launch_bounds__(256) void k_mesh(const MeshParams p) {
+    const int seg = blockIdx.y;
+    const int n = p.item_count[seg];
+    const PathSoA st = soa_offset(p.stage, p.seg_stage * seg);
+    const uint32_t *items = p.items + p.seg_items * seg;
+    unsigned long long *keys = p.keys + p.seg_keys * seg;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t item = items[k];
+        const int i = (int)(item & 0x3ffffffu), g = (int)(item >> 26);
+        Ray r;
+        r.o = V3(st.px[i], st.py[i], st.pz[i]);
+        r.d = V3(st.dx[i], st.dy[i], st.dz[i]);
+        const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r);
+        if (key != KEY_NONE) atomicMin(&keys[i], key);
     }
 }
 
@@ -807,6 +916,9 @@ struct ptx_tracer {
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr;   // pt_bvh.h (NULL: no mesh has one)
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
+    bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
+    unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
+    size_t seg_items = 0;
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
@@ -905,7 +1017,7 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
@@ -932,7 +1044,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     hipStream_t stream = lane == 0 ? t->stream : t->stream2;
     const size_t seg0 = (size_t)lane * t->kmax;
     const int nb = t->nbins;
-    const int triWords = t->tri_lds ? ((t->ntri_lds * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
+    const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
+    const int triWords = t->tri_lds ? ((ntri_lds * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
@@ -992,7 +1105,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             continue;
         }
         BounceParams bp;
-        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
+        bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->split_mesh ? 0 : t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
+        // (split: the mesh search runs in k_mesh from global memory, so the triangle tables need no LDS)
         const bool from_cache = (b == 1 && cache_on);           // with the cache on, bounce 0 always lands in soa[2]
         bp.in = from_cache ? t->soa[2] : soa_shift(t->soa[0], seg0 * t->cap);
         bp.stage = soa_shift(t->soa[1], seg0 * t->cap);
@@ -1013,8 +1127,25 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.part = batched ? t->d_part + seg0 * bp.seg_part : nullptr;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
-        if (first) KT(0, hipLaunchKernelGGL(k_bounce<true>, dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-        else KT(1, hipLaunchKernelGGL(k_bounce<false>, dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+        if (t->split_mesh) {
+            bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
+            bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
+            bp.item_count = t->d_item_count + seg0;
+            HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
+            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            else KT(1, hipLaunchKernelGGL((k_bounce<false, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            MeshParams mq;
+            mq.sc = t->scene();                                   // tables in global memory
+            mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
+            mq.seg_stage = bp.seg_stage; mq.seg_keys = bp.seg_keys; mq.seg_items = bp.seg_items;
+            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), 0, stream, mq));
+            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+        } else {
+            bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0;
+            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            else KT(1, hipLaunchKernelGGL((k_bounce<false, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+        }
 
         if (b + 1 < t->traceDepth) {
             MoveParams mp;
@@ -1154,6 +1285,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         const ptx_texture *tx[4] = {&g.kd, &g.ks, &g.ke, &g.bump};
         for (int k = 0; k < 4; k++) {
             DTex &dt = d.tex[k];
+            const char *dbg = getenv("PTX_DEBUG_DROP_TEX");          // timing experiments only: bit k drops texture k (kd ks ke bump)
+            if (dbg && ((atoi(dbg) >> k) & 1)) continue;
             if (tx[k]->channels > 0 && tx[k]->image && tx[k]->width > 0 && tx[k]->height > 0) {
                 if (tx[k]->channels < 3) { set_error(PTX_ERR_UNSUPPORTED, "textures need >= 3 channels"); return fail(PTX_ERR_UNSUPPORTED); }
                 dt.w = tx[k]->width; dt.h = tx[k]->height; dt.ch = tx[k]->channels; dt.off = htex.size();
@@ -1266,6 +1399,19 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
     if (kmax > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * nseg));
+    {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull) and a
+        // queue entry per (ray, mesh) pair in the worst case
+        int nmesh = 0;
+        for (int i = 0; i < ngeoms; i++) nmesh += hg[i].type == G_OBJ ? 1 : 0;
+        t->split_mesh = t->bvh_meshes > 0 && t->cull && !opt.no_mesh_split && nmesh <= SPLIT_MAX_MESHES && t->cap < (1 << 26);
+        if (getenv("PTX_DEBUG_FORCE_SPLIT")) t->split_mesh = t->cull && nmesh >= 1 && nmesh <= SPLIT_MAX_MESHES;      // timing experiments only
+        if (t->split_mesh) {
+            t->seg_items = (size_t)t->cap * nmesh;
+            HC(hipMalloc(&t->d_keys, sizeof(unsigned long long) * (size_t)t->cap * nseg));
+            HC(hipMalloc(&t->d_items, sizeof(uint32_t) * t->seg_items * nseg));
+            HC(hipMalloc(&t->d_item_count, sizeof(int32_t) * nseg));
+        }
+    }
     if (opt.apps_variant) {
         HC(hipMalloc(&t->d_albedo, sizeof(float) * 3 * npix));
         HC(hipMemset(t->d_albedo, 0, sizeof(float) * 3 * npix));

@@ -155,6 +155,8 @@ def oracle_pending_stream(O, it, bounce):
     ("cornellSpaceship.txt", (96, 54), 8, dict(no_bvh=1)),                 # the reference's loop over all faces
     ("cornellSpaceship20k.txt", (64, 36), 8, dict(depth_of_field=1)),      # 20448 triangles: BVH, tables in global memory
     ("cornellSpaceship20k.txt", (64, 36), 8, dict(no_cull=1)),
+    ("cornellSpaceship20k.txt", (64, 36), 8, dict(no_mesh_split=1)),      # mesh search inside the bounce kernel
+    ("cornellSpaceship.txt", (96, 54), 8, dict(no_mesh_split=1, depth_of_field=1)),
     ("cornellGlass.txt", (96, 54), 12, dict(no_cull=1)),
 ])
 def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
