@@ -51,6 +51,9 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #ifndef PT_TILE
 #define PT_TILE 256
 #endif
+#ifndef PT_MESH_WAVES
+#define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
+#endif
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4     // waves per SIMD k_bounce is compiled for (register budget 512 / this)
 #endif
@@ -615,7 +618,7 @@ struct MeshParams {
     unsigned long long *keys; const uint32_t *items; const int32_t *item_count;
     size_t seg_stage, seg_keys, seg_items;
 };
-__global__ __launch_bounds__(256) void k_mesh(const MeshParams p) {
+__global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p) {
     const int seg = blockIdx.y;
     const int n = p.item_count[seg];
     const PathSoA st = soa_offset(p.stage, p.seg_stage * seg);
@@ -1756,6 +1759,7 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
         float b0, b1;
         t_loop[i] = loopNearestHost(faces15, tri9.data(), nfaces, o, d, f0);
         t_bvh[i] = bvhNearest(bb.nodes.data(), bb.tris.data(), root, o, d, f1, b0, b1, &vis);
+        if (getenv("PTX_DEBUG_BVH_VISITS")) t_loop[i] = (float)vis;      // experiments: per-ray visit counts instead of the loop's t
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;
     }
