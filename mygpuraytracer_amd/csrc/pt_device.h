@@ -200,6 +200,10 @@ struct DCamera {                        // = struct Camera, src/sceneStructs.h:8
     float position[3], lookAt[3], view[3], up[3], right[3], fov[2], pixelLength[2];
 };
 struct alignas(16) BvhQuad { float x, y, z; int32_t w; };
+#ifndef PT_MESH_CHUNK
+#define PT_MESH_CHUNK 4
+#endif
+constexpr int MESH_CHUNK = PT_MESH_CHUNK;            // faces per lane when a small mesh's loop is spread over lanes
 constexpr int BVH_LEAF_MAX = 4;
 constexpr int BVH_MIN_FACES = 24;        // meshes smaller than this keep the plain loop
 struct DScene {
@@ -221,6 +225,8 @@ struct DScene {
     const BvhQuad *__restrict__ bvh_nodes;          // threaded BVH of the larger meshes (pt_bvh.h), or NULL
     const float *__restrict__ bvh_tris;             // 16 floats per leaf triangle
     const int32_t *__restrict__ bvh_root;           // per geom: root node, -1 = plain loop over its faces
+    int32_t mesh_chunks;                // > 1: no mesh has a BVH and the longest has this many groups of MESH_CHUNK faces:
+                                        // tileIntersect spreads every (ray, mesh) pair over that many lanes
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
@@ -433,7 +439,7 @@ PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restric
 
 // meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space
 // distance, as the reference does.  (intersectionPoint, which the reference also fills, has no reader.)
-PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, int bvhRoot = -1) {
+PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, int bvhRoot = -1, int j0 = 0, int j1 = 0x7fffffff) {
     Ray q;
     q.o = multiplyMV(geom.inv, r.o, 1.0f);
     q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
@@ -453,7 +459,8 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
         if (nearest == -1) return -1.f;
         return tmin;
     }
-    for (int j = 0; j < geom.faceCount; j++) {
+    if (j1 > geom.faceCount) j1 = geom.faceCount;
+    for (int j = j0; j < j1; j++) {       // (the whole face list unless the caller spreads it over lanes)
         vec3 v0, e1, e2;
         if (sc.tri_lds && sc.ntri_lds) {      // broadcast ds_reads: every lane reads the same triangle
             const float *t9 = reinterpret_cast<const float *>(pt_lds) + (size_t)(geom.faceStart + j) * 9;
@@ -711,7 +718,7 @@ PT_DEV unsigned long long primKey(const float *gtab, int g, Ray ray) {
 }
 
 // mesh g against one ray (g may differ per lane: its header is gathered from LDS)
-PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ray ray) {
+PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ray ray, int chunk = -1) {
     const float *G = gtab + g * GTAB_WORDS;
     DGeom geom;
     // rows -> glm column-major for the shared mesh routine: only inv is read there
@@ -723,7 +730,15 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
     geom.faceStart = __float_as_int(G[38]); geom.faceCount = __float_as_int(G[39]);
     Cand c;
     c.face = -1; c.u = 0.f; c.v = 0.f;
-    const float t = meshTestCore(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1);
+    // chunk >= 0: faces [chunk * MESH_CHUNK, +MESH_CHUNK) only; the minimum over a mesh's chunks of (t, geom, face) is
+    // the loop's answer: nearest distance, lowest face index on ties
+    float t;
+    if (chunk >= 0) {
+        if (chunk * MESH_CHUNK >= geom.faceCount) return KEY_NONE;
+        t = meshTestCore(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
+    } else {
+        t = meshTestCore(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1);
+    }
     if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
     return packKey(t, g, (uint32_t)c.face);
 }

@@ -269,18 +269,25 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
         if (tid == 0) { st_acc[8] += totC + totS; st_acc[9] += totM; st_acc[10] += 1; }
 #endif
         // each kind starts on a wave boundary: cubes [0, totC), spheres from roundup64(totC), meshes after them
+        // small meshes (no BVH in the scene): every (ray, mesh) pair becomes mesh_chunks entries, one per group of
+        // MESH_CHUNK faces, chunk-major so that a wave reads the same faces
         const int startS = (totC + 63) & ~63, startM = startS + ((totS + 63) & ~63);
-        for (int k = tid; k < startM + totM; k += TILE) {
-            int item = -1;
+        const int nch = sc.mesh_chunks > 1 ? sc.mesh_chunks : 1;
+        for (int k = tid; k < startM + totM * nch; k += TILE) {
+            int item = -1, chunk = -1;
             if (k < totC) item = list[k];
             else if (k >= startS && k < startS + totS) item = list[CAP - 1 - (k - startS)];
-            else if (k >= startM) item = listM[k - startM];
+            else if (k >= startM) {
+                int kk = k - startM;
+                if (nch > 1) { chunk = 0; while (kk >= totM) { kk -= totM; chunk++; } }
+                item = listM[kk];
+            }
             if (item >= 0) {
                 const int src = item & 0xff, g = item >> 8;
                 Ray r;
                 r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
                 r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
-                const unsigned long long key = k < startM ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r);
+                const unsigned long long key = k < startM ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r, chunk);
                 if (key != KEY_NONE) atomicMin(&best[src], key);
             }
         }
@@ -919,6 +926,7 @@ struct ptx_tracer {
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr;   // pt_bvh.h (NULL: no mesh has one)
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
+    int mesh_chunks = 1;                                 // see DScene::mesh_chunks
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
     unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
     size_t seg_items = 0;
@@ -954,7 +962,7 @@ struct ptx_tracer {
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
-        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.ntri_lds = 0;
+        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -1317,6 +1325,9 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
                 t->bvh_meshes++;
             }
         t->bvh_nodes = (int)(bb.nodes.size() / 2);
+        if (!t->bvh_meshes && !getenv("PTX_DEBUG_NO_CHUNKS"))          // spread the loops of small meshes over lanes (tileIntersect)
+            for (int i = 0; i < ngeoms; i++)
+                if (hg[i].type == G_OBJ) t->mesh_chunks = std::max(t->mesh_chunks, (hg[i].faceCount + MESH_CHUNK - 1) / MESH_CHUNK);
         if (t->bvh_meshes) {
             HC(hipMalloc(&t->d_bvh_nodes, sizeof(BvhQuad) * bb.nodes.size()));
             HC(hipMemcpy(t->d_bvh_nodes, bb.nodes.data(), sizeof(BvhQuad) * bb.nodes.size(), hipMemcpyHostToDevice));
