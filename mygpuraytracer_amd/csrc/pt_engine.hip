@@ -362,7 +362,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
 #ifdef PT_STAMPS
-    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
 #define STAMP(k) do { st_t1 = __builtin_amdgcn_s_memtime(); st_acc[k] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -493,7 +493,9 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             // in batched mode the path's slot of the per-iteration buffer must still be written
             if (part && !pending && !lit) {
                 float *px = part + (size_t)pix * 3;
-                px[0] = 0.f; px[1] = 0.f; px[2] = 0.f;
+                float z = 0.f;
+                asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
+                px[0] = z; px[1] = z; px[2] = z;
             }
         }
         STAMP(2);        // classify + deposit
@@ -519,30 +521,38 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 remaining &= ~m_all;
             }
         }
+        STAMP(12);       // (ranking: ballots)
         __syncthreads();
+        STAMP(13);       // (ranking: wait at its first barrier)
         if (alive) {
             for (int w = 0; w < wave; w++) { r_all += w_all[w * nb + bin]; r_scat += w_scat[w * nb + bin]; }
         }
         if (nb <= 64) {
             // wave 0: lane b owns bin b -- tile counts, running prefixes and the in-tile offsets by a wave scan
             if (wave == 0) {
+                // `ln` = lane, but opaque to the optimiser: otherwise the per-lane addresses below are loop invariants,
+                // get hoisted out of the tile loop, and -- the kernel being at its register limit -- are spilled to
+                // scratch, whose reloads (memory latency, one after the other) then sit on every tile's critical path
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
                 int ca = 0, cs = 0;
-                if (lane < nb) {
-                    for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + lane]; cs += w_scat[w * nb + lane]; }
-                    counts_all[(size_t)lane * p.maxTiles + tile] = run_all[lane];
-                    counts_scat[(size_t)lane * p.maxTiles + tile] = run_scat[lane];
-                    run_all[lane] += ca;
-                    run_scat[lane] += cs;
+                if (ln < nb) {
+                    for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + ln]; cs += w_scat[w * nb + ln]; }
+                    counts_all[(size_t)ln * p.maxTiles + tile] = run_all[ln];
+                    counts_scat[(size_t)ln * p.maxTiles + tile] = run_scat[ln];
+                    run_all[ln] += ca;
+                    run_scat[ln] += cs;
                 }
                 int inc = cs;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const int a = __shfl_up(inc, off);
-                    if (lane >= off) inc += a;
+                    if (ln >= off) inc += a;
                 }
-                if (lane < nb) toff[lane] = inc - cs;
-                if (lane == nb - 1) toff[nb] = inc;
+                if (ln < nb) toff[ln] = inc - cs;
+                if (ln == nb - 1) toff[nb] = inc;
             }
+            STAMP(14);   // (ranking: counts, wave 0's scan)
             __syncthreads();
         } else {
             for (int b = tid; b < nb; b += TILE) {
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     }
 #ifdef PT_STAMPS
     if (lane == 0 && p.stamps)
-        for (int k = 0; k < 12; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
+        for (int k = 0; k < 16; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
 #endif
     if (MODE == 1) {                     // counts belong to MODE 2; what is left in the LDS queue goes out now
         if (*qcnt > 0) flushQueue(p, seg, qbuf, qcnt, qbase, tid);

@@ -17,9 +17,9 @@ L.ptx_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 out = np.zeros(32, np.uint64)
 T.render(1, 16); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
 T.render(17, 64); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
-names = {0: "load+shade/gen", 1: "isect-rest", 2: "classify+deposit", 3: "ranking", 4: "sort+write", 5: "cull+list", 6: "items", 7: "decode", 11: "load-wait"}
+names = {0: "load+shade/gen", 1: "isect-rest", 2: "classify+deposit", 3: "ranking", 4: "sort+write", 5: "cull+list", 6: "items", 7: "decode", 11: "load-wait", 12: "rank-ballots", 13: "rank-wait1", 14: "rank-counts"}
 for base, tag in ((0, "k_bounce<first>"), (16, "k_bounce")):
-    tot = float(out[base:base + 8].sum() + out[base + 11])
-    print(tag, " ".join("%s %.1f%%" % (names[k], 100 * float(out[base + k]) / max(tot, 1)) for k in list(range(8)) + [11]), "total cycles %.3g" % tot)
+    tot = float(out[base:base + 8].sum() + out[base + 11:base + 15].sum())
+    print(tag, " ".join("%s %.1f%%" % (names[k], 100 * float(out[base + k]) / max(tot, 1)) for k in list(range(8)) + [11, 12, 13, 14]), "total cycles %.3g" % tot)
     passes = max(float(out[base + 10]), 1)
     print("   per tile-pass: prim items %.1f mesh items %.1f (passes %d)" % (float(out[base + 8]) / passes, float(out[base + 9]) / passes, passes))
