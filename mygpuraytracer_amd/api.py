@@ -15,6 +15,7 @@ Nothing here computes: every call goes through the library, and there is no CPU 
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -83,11 +84,34 @@ class Orbit(C.Structure):
     _fields_ = [("phi", C.c_float), ("theta", C.c_float), ("zoom", C.c_float), ("og_look_at", C.c_float * 3)]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch's ROCm wheels bundle their own HIP runtime under torch/lib with the same sonames as /opt/rocm's.
+    Whichever copy a process loads first serves both libraries, and torch does not find its GPUs through the system
+    copy -- so a process that may import torch later (the multi-GPU driver does) loads torch's copy first.
+    Without torch installed this does nothing and the library uses /opt/rocm's runtime."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Loads the native library; raises loudly when it has not been built -- there is no fallback."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise PathTracerError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(or make -C mygpuraytracer_amd/csrc). There is no CPU fallback." % LIB_PATH)
