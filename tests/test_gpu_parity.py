@@ -252,6 +252,32 @@ def test_full_size_c4_counts_and_properties(gpu_product, O):
     T.close(); T2.close()
 
 
+@pytest.mark.parametrize("tag,scene,res,depth,opt", [
+    ("c1", "sphere.txt", (256, 256), 4, {}),
+    ("c2", "cornell.txt", (800, 800), 8, dict(antialiasing=0)),
+    ("c3", "cornellGlass.txt", (1920, 1080), 12, {}),
+])
+def test_full_size_c1_c2_c3_against_the_reference(gpu_product, tag, scene, res, depth, opt):
+    """The other BASELINE configs at their full sizes: rays per bounce of iteration 1 and the image's channel and row
+    sums (float64 sums of the fp32 frame) equal what the reference build produced (tests/golden/fullres_counts.npz)."""
+    f = golden("fullres_counts.npz")
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=depth)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s, **opt) as T:
+        T.pathtrace(1)
+        img = T.read_image()
+        want = f[tag + "_counts"].tolist()               # the reference's loop stops at the first empty bounce
+        got = T.stats()["rays_per_bounce"]
+        assert got[:len(want)] == want and not any(got[len(want):])
+        assert np.array_equal(img.sum(axis=0, dtype=np.float64), f[tag + "_image_sum"])
+        assert np.array_equal(img.reshape(res[1], res[0], 3).sum(axis=(1, 2), dtype=np.float64), f[tag + "_image_rowsum"])
+        T.render(2, 9)                                   # iterations 2..10 batched on two streams (C2: from the cache)
+        ten = T.read_image()
+    with gpu_product.Tracer(s, batch=1, lanes=1, **opt) as T:
+        T.render(1, 10)
+        assert beq(T.read_image(), ten)
+
+
 def test_full_size_c4_against_oracle(gpu_product, O):
     """One whole 1920x1080 iteration against the CPU oracle (about 4 s of CPU): identical image."""
     s, T = make_pair(gpu_product, O, "cornellObj.txt", (1920, 1080), 8)
