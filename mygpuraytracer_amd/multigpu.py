@@ -17,7 +17,7 @@ into the torch tensor that RCCL reduces) and, in the CPU tests, over gloo with a
 import torch
 import torch.distributed as dist
 
-TILE_ROWS = 16
+TILE_ROWS = 8
 
 
 def owned_rows(height, tile_rows, rank, world):

@@ -95,9 +95,9 @@ def test_owned_rows_rule():
         for r in range(world):
             seen += multigpu.owned_rows(H, rows, r, world)
         assert sorted(seen) == list(range(H))
-    # balance at the bench geometry: 1080 rows, 16-row blocks, 8 ranks -> 128..144 rows each
-    sizes = [len(multigpu.owned_rows(1080, 16, r, 8)) for r in range(8)]
-    assert max(sizes) - min(sizes) <= 16
+    # balance at the bench geometry: 1080 rows, TILE_ROWS-row blocks, 8 ranks -> 128..136 rows each
+    sizes = [len(multigpu.owned_rows(1080, multigpu.TILE_ROWS, r, 8)) for r in range(8)]
+    assert max(sizes) - min(sizes) <= multigpu.TILE_ROWS
 
 
 # ---- iteration sharding: rank r traces iterations r+1, r+1+N, ... of the full frame ---------------------------------
