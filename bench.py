@@ -63,7 +63,29 @@ def cpu_baseline(scene, iters):
         c = SC.cpu_compact_with_scan(flags); ms["cpu_with_scan"] += SC.last_cpu_ms()
         g = SC.efficient_compact(flags); ms["gpu_efficient_compact"] += SC.last_gpu_ms()
         assert len(a) == len(c) == len(g) == alive
-    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
+    # the reference's own code (oracle/_ref: its headers and loader compiled for the host, where it has been built) on
+    # three iterations of the same frame, next to the port
+    reference = None
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
+    if os.path.exists(ref_so):
+        try:
+            from cpulibs import RefLib, scene_text_with
+            R = RefLib(ref_so)
+            text = scene_text_with(open(os.path.join(ROOT, "scenes", SCENE)).read(), RES, DEPTH)
+            R.load_text(text, cwd=os.path.join(ROOT, "scenes"))
+            R.apply_runcuda_camera()
+            R.pt_init()
+            t1 = time.time()
+            rrays = 0
+            for it in range(1, 4):
+                R.iterate(it)
+                rrays += int(R.live_counts().sum())
+            rdt = time.time() - t1
+            reference = dict(value=rrays / rdt / 1e6, unit="Mrays/s", cores=1,
+                             sample="3 iterations, %.1f s, the reference's intersections.h / interactions.h built host-only (oracle/_ref)" % rdt)
+        except Exception as e:                      # the baseline is optional, the bench line is not
+            reference = dict(error=str(e)[:200])
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port", reference=reference,
                 stream_compaction_ms_per_iteration=dict(elements=sum(counts), **ms),
                 sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
