@@ -66,12 +66,30 @@ constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8) +
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
 struct PathSoA {
-    float *px, *py, *pz;                                 // shading point = origin + t * direction (src/pathtrace.cu:392)
-    float *dx, *dy, *dz, *cr, *cg, *cb;                  // incoming direction, throughput colour
-    float *nx, *ny, *nz, *u, *v;                         // pending intersection: normal, texcoord (u, v only if textured)
-    int32_t *pix;                                        // pixelIndex (global, x + y*W)
-    int32_t *mg;                                         // materialId | geomId << 16
-    int32_t *idx;                                        // stream: RNG stream index; stage: key (see stage_key) or -1
+    // field k of the floats starts at f + k * stride, of the ints at i + k * stride (stride = segments x capacity; a
+    // segment's part of a field starts seg * capacity further).  Kept as base + stride rather than 17 pointers: a kernel
+    // that holds two of these in scalar registers for its whole tile loop has none left for anything else.
+    float *f;
+    int32_t *i;
+    uint32_t stride;
+    __host__ __device__ float *field(int k) const { return f + (size_t)k * stride; }
+    __host__ __device__ float *px() const { return field(0); }      // shading point = origin + t * direction (src/pathtrace.cu:392)
+    __host__ __device__ float *py() const { return field(1); }
+    __host__ __device__ float *pz() const { return field(2); }
+    __host__ __device__ float *dx() const { return field(3); }      // incoming direction
+    __host__ __device__ float *dy() const { return field(4); }
+    __host__ __device__ float *dz() const { return field(5); }
+    __host__ __device__ float *cr() const { return field(6); }      // throughput colour
+    __host__ __device__ float *cg() const { return field(7); }
+    __host__ __device__ float *cb() const { return field(8); }
+    __host__ __device__ float *nx() const { return field(9); }      // pending intersection: normal, texcoord (u, v only if textured)
+    __host__ __device__ float *ny() const { return field(10); }
+    __host__ __device__ float *nz() const { return field(11); }
+    __host__ __device__ float *u() const { return field(12); }
+    __host__ __device__ float *v() const { return field(13); }
+    __host__ __device__ int32_t *pix() const { return i; }                          // pixelIndex (global, x + y*W)
+    __host__ __device__ int32_t *mg() const { return i + (size_t)stride; }          // materialId | geomId << 16
+    __host__ __device__ int32_t *idx() const { return i + 2 * (size_t)stride; }     // stream: RNG stream index; stage: key (see stage_key) or -1
 };
 constexpr int SOA_FLOATS = 14, SOA_INTS = 3;
 
@@ -79,9 +97,14 @@ constexpr int SOA_FLOATS = 14, SOA_INTS = 3;
 __device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << 16) | ((uint32_t)r_scat << 24)); }
 
 __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
-    s.px += off; s.py += off; s.pz += off; s.dx += off; s.dy += off; s.dz += off; s.cr += off; s.cg += off; s.cb += off;
-    s.nx += off; s.ny += off; s.nz += off; s.u += off; s.v += off;
-    s.pix += off; s.mg += off; s.idx += off;
+    s.f += off; s.i += off;
+    return s;
+}
+// The same stream, but with a stride the optimiser cannot see through: field addresses derived from the result are
+// computed where they are used (a few scalar adds per tile) instead of being hoisted out of the tile loop and kept --
+// 34 scalar registers per stream -- for its whole length.
+__device__ __forceinline__ PathSoA soa_fresh(PathSoA s) {
+    asm volatile("" : "+s"(s.stride));
     return s;
 }
 
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     __syncthreads();
     const int seg = blockIdx.y;
     const int iter = p.iter + seg * p.iter_stride;
-    const PathSoA in = soa_offset(p.in, p.seg_in * seg), stage = soa_offset(p.stage, p.seg_stage * seg);
+    const PathSoA in_k = soa_offset(p.in, p.seg_in * seg), stage_k = soa_offset(p.stage, p.seg_stage * seg);
     int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
     int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
     int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
@@ -373,6 +396,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
 #endif
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
+        const PathSoA in = soa_fresh(in_k), stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
         int pix = 0;
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
@@ -381,11 +405,11 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         if (MODE == 2) {                 // parked by MODE 1 in this tile's stage slots
             alive = false;
             if (i < n_in) {
-                pix = stage.pix[i];
+                pix = stage.pix()[i];
                 alive = pix >= 0;
-                ps.o = V3(stage.px[i], stage.py[i], stage.pz[i]);
-                ps.d = V3(stage.dx[i], stage.dy[i], stage.dz[i]);
-                ps.color = V3(stage.cr[i], stage.cg[i], stage.cb[i]);
+                ps.o = V3(stage.px()[i], stage.py()[i], stage.pz()[i]);
+                ps.d = V3(stage.dx()[i], stage.dy()[i], stage.dz()[i]);
+                ps.color = V3(stage.cr()[i], stage.cg()[i], stage.cb()[i]);
                 key = (p.keys + p.seg_keys * seg)[i];
             }
         } else if (alive) {
@@ -396,18 +420,18 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                const vec3 intersect = V3(in.px[i], in.py[i], in.pz[i]);     // stored as origin + t * direction
-                ps.d = V3(in.dx[i], in.dy[i], in.dz[i]);
-                ps.color = V3(in.cr[i], in.cg[i], in.cb[i]);
-                pix = in.pix[i];
+                const vec3 intersect = V3(in.px()[i], in.py()[i], in.pz()[i]);     // stored as origin + t * direction
+                ps.d = V3(in.dx()[i], in.dy()[i], in.dz()[i]);
+                ps.color = V3(in.cr()[i], in.cg()[i], in.cb()[i]);
+                pix = in.pix()[i];
                 Hit h;
                 h.t = 1.f;
-                h.n = V3(in.nx[i], in.ny[i], in.nz[i]);
+                h.n = V3(in.nx()[i], in.ny()[i], in.nz()[i]);
                 h.u = 0.f; h.v = 0.f;
-                if (p.uses_uv) { h.u = in.u[i]; h.v = in.v[i]; }
-                int mg = in.mg[i];
+                if (p.uses_uv) { h.u = in.u()[i]; h.v = in.v()[i]; }
+                int mg = in.mg()[i];
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
-                const int sidx = in.idx[i];
+                const int sidx = in.idx()[i];
 #ifdef PT_STAMPS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 STAMP(11);
@@ -433,10 +457,10 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
                 // park the ray and queue its mesh candidates: per mesh present in the wave one atomic for the base
                 if (i < n_in) {
-                    stage.px[i] = ray.o.x; stage.py[i] = ray.o.y; stage.pz[i] = ray.o.z;
-                    stage.dx[i] = ray.d.x; stage.dy[i] = ray.d.y; stage.dz[i] = ray.d.z;
-                    stage.cr[i] = ps.color.x; stage.cg[i] = ps.color.y; stage.cb[i] = ps.color.z;
-                    stage.pix[i] = alive ? pix : -1;
+                    stage.px()[i] = ray.o.x; stage.py()[i] = ray.o.y; stage.pz()[i] = ray.o.z;
+                    stage.dx()[i] = ray.d.x; stage.dy()[i] = ray.d.y; stage.dz()[i] = ray.d.z;
+                    stage.cr()[i] = ps.color.x; stage.cg()[i] = ps.color.y; stage.cb()[i] = ps.color.z;
+                    stage.pix()[i] = alive ? pix : -1;
                     (p.keys + p.seg_keys * seg)[i] = key;
                 }
                 // queue entries go through an LDS buffer (the upper part of `rec`, free in this mode) and reach the global
@@ -590,20 +614,21 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         }
         __syncthreads();
         {
+            const PathSoA stage = soa_fresh(stage_k);
             const int npend = toff[nb];
             const size_t gi = (size_t)tile * TILE + tid;
             if (tid < npend) {
                 const float *rf = reinterpret_cast<const float *>(rec);
-                stage.px[gi] = rf[0 * TILE + tid]; stage.py[gi] = rf[1 * TILE + tid]; stage.pz[gi] = rf[2 * TILE + tid];
-                stage.dx[gi] = rf[3 * TILE + tid]; stage.dy[gi] = rf[4 * TILE + tid]; stage.dz[gi] = rf[5 * TILE + tid];
-                stage.cr[gi] = rf[6 * TILE + tid]; stage.cg[gi] = rf[7 * TILE + tid]; stage.cb[gi] = rf[8 * TILE + tid];
-                stage.nx[gi] = rf[9 * TILE + tid]; stage.ny[gi] = rf[10 * TILE + tid]; stage.nz[gi] = rf[11 * TILE + tid];
-                if (p.uses_uv) { stage.u[gi] = rf[12 * TILE + tid]; stage.v[gi] = rf[13 * TILE + tid]; }
-                stage.pix[gi] = rec[14 * TILE + tid];
-                stage.mg[gi] = rec[15 * TILE + tid];
-                stage.idx[gi] = rec[16 * TILE + tid];
+                stage.px()[gi] = rf[0 * TILE + tid]; stage.py()[gi] = rf[1 * TILE + tid]; stage.pz()[gi] = rf[2 * TILE + tid];
+                stage.dx()[gi] = rf[3 * TILE + tid]; stage.dy()[gi] = rf[4 * TILE + tid]; stage.dz()[gi] = rf[5 * TILE + tid];
+                stage.cr()[gi] = rf[6 * TILE + tid]; stage.cg()[gi] = rf[7 * TILE + tid]; stage.cb()[gi] = rf[8 * TILE + tid];
+                stage.nx()[gi] = rf[9 * TILE + tid]; stage.ny()[gi] = rf[10 * TILE + tid]; stage.nz()[gi] = rf[11 * TILE + tid];
+                if (p.uses_uv) { stage.u()[gi] = rf[12 * TILE + tid]; stage.v()[gi] = rf[13 * TILE + tid]; }
+                stage.pix()[gi] = rec[14 * TILE + tid];
+                stage.mg()[gi] = rec[15 * TILE + tid];
+                stage.idx()[gi] = rec[16 * TILE + tid];
             } else {
-                stage.idx[gi] = -1;
+                stage.idx()[gi] = -1;
             }
         }
         __syncthreads();
@@ -645,8 +670,8 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p)
         const uint32_t item = items[k];
         const int i = (int)(item & 0x3ffffffu), g = (int)(item >> 26);
         Ray r;
-        r.o = V3(st.px[i], st.py[i], st.pz[i]);
-        r.d = V3(st.dx[i], st.dy[i], st.dz[i]);
+        r.o = V3(st.px()[i], st.py()[i], st.pz()[i]);
+        r.d = V3(st.dx()[i], st.dy()[i], st.dz()[i]);
         const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r);
         if (key != KEY_NONE) atomicMin(&keys[i], key);
     }
@@ -666,7 +691,7 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
     const int nb = p.nbins, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *base_all = pt_lds, *base_scat = pt_lds + nb;          // dynamic LDS: base_all[nb], base_scat[nb]
     const int seg = blockIdx.y;
-    const PathSoA stage = soa_offset(p.stage, p.seg_stage * seg), out = soa_offset(p.out, p.seg_out * seg);
+    const PathSoA stage_k = soa_offset(p.stage, p.seg_stage * seg), out_k = soa_offset(p.out, p.seg_out * seg);
     const int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
     const int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
     const int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
@@ -696,13 +721,14 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
     // latency here (one tile's 15 loads per lane in flight is not enough at 8 waves per SIMD)
     constexpr int MOVE_U = 4;
     for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
+        const PathSoA stage = soa_fresh(stage_k), out = soa_fresh(out_k);
         size_t i[MOVE_U];
         int32_t key[MOVE_U];
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
             const int tile = tbase + u;
             i[u] = (size_t)min(tile, tile1 - 1) * TILE + tid;
-            key[u] = stage.idx[i[u]];
+            key[u] = stage.idx()[i[u]];
             if (tile >= tile1) key[u] = -1;
         }
         float f[MOVE_U][14];
@@ -710,12 +736,12 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
             if (key[u] != -1) {
-                f[u][0] = stage.px[i[u]]; f[u][1] = stage.py[i[u]]; f[u][2] = stage.pz[i[u]];
-                f[u][3] = stage.dx[i[u]]; f[u][4] = stage.dy[i[u]]; f[u][5] = stage.dz[i[u]];
-                f[u][6] = stage.cr[i[u]]; f[u][7] = stage.cg[i[u]]; f[u][8] = stage.cb[i[u]];
-                f[u][9] = stage.nx[i[u]]; f[u][10] = stage.ny[i[u]]; f[u][11] = stage.nz[i[u]];
-                if (p.uses_uv) { f[u][12] = stage.u[i[u]]; f[u][13] = stage.v[i[u]]; }
-                pixv[u] = stage.pix[i[u]]; mgv[u] = stage.mg[i[u]];
+                f[u][0] = stage.px()[i[u]]; f[u][1] = stage.py()[i[u]]; f[u][2] = stage.pz()[i[u]];
+                f[u][3] = stage.dx()[i[u]]; f[u][4] = stage.dy()[i[u]]; f[u][5] = stage.dz()[i[u]];
+                f[u][6] = stage.cr()[i[u]]; f[u][7] = stage.cg()[i[u]]; f[u][8] = stage.cb()[i[u]];
+                f[u][9] = stage.nx()[i[u]]; f[u][10] = stage.ny()[i[u]]; f[u][11] = stage.nz()[i[u]];
+                if (p.uses_uv) { f[u][12] = stage.u()[i[u]]; f[u][13] = stage.v()[i[u]]; }
+                pixv[u] = stage.pix()[i[u]]; mgv[u] = stage.mg()[i[u]];
             }
         }
 #pragma unroll
@@ -725,14 +751,14 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
             const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
             const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + r_all;
             const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + r_scat;
-            out.px[pos] = f[u][0]; out.py[pos] = f[u][1]; out.pz[pos] = f[u][2];
-            out.dx[pos] = f[u][3]; out.dy[pos] = f[u][4]; out.dz[pos] = f[u][5];
-            out.cr[pos] = f[u][6]; out.cg[pos] = f[u][7]; out.cb[pos] = f[u][8];
-            out.nx[pos] = f[u][9]; out.ny[pos] = f[u][10]; out.nz[pos] = f[u][11];
-            if (p.uses_uv) { out.u[pos] = f[u][12]; out.v[pos] = f[u][13]; }
-            out.pix[pos] = pixv[u];
-            out.mg[pos] = mgv[u];
-            out.idx[pos] = idx;
+            out.px()[pos] = f[u][0]; out.py()[pos] = f[u][1]; out.pz()[pos] = f[u][2];
+            out.dx()[pos] = f[u][3]; out.dy()[pos] = f[u][4]; out.dz()[pos] = f[u][5];
+            out.cr()[pos] = f[u][6]; out.cg()[pos] = f[u][7]; out.cb()[pos] = f[u][8];
+            out.nx()[pos] = f[u][9]; out.ny()[pos] = f[u][10]; out.nz()[pos] = f[u][11];
+            if (p.uses_uv) { out.u()[pos] = f[u][12]; out.v()[pos] = f[u][13]; }
+            out.pix()[pos] = pixv[u];
+            out.mg()[pos] = mgv[u];
+            out.idx()[pos] = idx;
         }
     }
 }
@@ -983,15 +1009,11 @@ namespace {
 
 // field arrays of `stride` elements each (stride = segments x cap: segment s of a field starts at s*cap)
 void carve(PathSoA &s, float *f, int32_t *i, size_t stride) {
-    float **fp[SOA_FLOATS] = {&s.px, &s.py, &s.pz, &s.dx, &s.dy, &s.dz, &s.cr, &s.cg, &s.cb, &s.nx, &s.ny, &s.nz, &s.u, &s.v};
-    for (int k = 0; k < SOA_FLOATS; k++) *fp[k] = f + (size_t)k * stride;
-    s.pix = i; s.mg = i + stride; s.idx = i + 2 * stride;
+    s.f = f; s.i = i; s.stride = (uint32_t)stride;
 }
 
 PathSoA soa_shift(PathSoA s, size_t off) {       // host side of soa_offset: the same fields `off` elements further
-    s.px += off; s.py += off; s.pz += off; s.dx += off; s.dy += off; s.dz += off; s.cr += off; s.cg += off; s.cb += off;
-    s.nx += off; s.ny += off; s.nz += off; s.u += off; s.v += off;
-    s.pix += off; s.mg += off; s.idx += off;
+    s.f += off; s.i += off;
     return s;
 }
 
@@ -1190,13 +1212,13 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
             const PathSoA &src = (first && cache_on) ? t->soa[2] : t->soa[0];
             size_t cb = sizeof(int32_t) * (size_t)t->cap;
-            HIPCHECK(hipMemcpyAsync(t->d_cap, src.pix, cb, hipMemcpyDeviceToDevice, stream));
-            HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx, cb, hipMemcpyDeviceToDevice, stream));
-            HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg, cb, hipMemcpyDeviceToDevice, stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap, src.pix(), cb, hipMemcpyDeviceToDevice, stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx(), cb, hipMemcpyDeviceToDevice, stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg(), cb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
             const size_t fstride = (first && cache_on) ? (size_t)t->cap : t->field_stride;
             for (int f = 0; f < SOA_FLOATS; f++)
-                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.px + (size_t)f * fstride,
+                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.field(f),
                                         sizeof(float) * (size_t)t->cap, hipMemcpyDeviceToDevice, stream));
             t->cap_filled = true;
         }
