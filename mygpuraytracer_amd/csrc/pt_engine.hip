@@ -1328,8 +1328,6 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         const ptx_texture *tx[4] = {&g.kd, &g.ks, &g.ke, &g.bump};
         for (int k = 0; k < 4; k++) {
             DTex &dt = d.tex[k];
-            const char *dbg = getenv("PTX_DEBUG_DROP_TEX");          // timing experiments only: bit k drops texture k (kd ks ke bump)
-            if (dbg && ((atoi(dbg) >> k) & 1)) continue;
             if (tx[k]->channels > 0 && tx[k]->image && tx[k]->width > 0 && tx[k]->height > 0) {
                 if (tx[k]->channels < 3) { set_error(PTX_ERR_UNSUPPORTED, "textures need >= 3 channels"); return fail(PTX_ERR_UNSUPPORTED); }
                 dt.w = tx[k]->width; dt.h = tx[k]->height; dt.ch = tx[k]->channels; dt.off = htex.size();
@@ -1809,7 +1807,6 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
         float b0, b1;
         t_loop[i] = loopNearestHost(faces15, tri9.data(), nfaces, o, d, f0);
         t_bvh[i] = bvhNearest(bb.nodes.data(), bb.tris.data(), root, o, d, f1, b0, b1, &vis);
-        if (getenv("PTX_DEBUG_BVH_VISITS")) t_loop[i] = (float)vis;      // experiments: per-ray visit counts instead of the loop's t
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;
     }

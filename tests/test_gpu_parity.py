@@ -295,6 +295,24 @@ def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product):
     assert np.isfinite(fast).all() and (fast >= 0).all() and fast.max() > 0
 
 
+def test_tuning_knobs_do_not_change_results(gpu_product, O, monkeypatch):
+    """The environment knobs of the library only choose between equivalent execution plans: split mesh search forced on a
+    scene whose mesh has no BVH (k_mesh then runs the plain loop), small-mesh loops not spread over lanes, another grid."""
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", (160, 90), 8)
+    for it in (1, 2, 3):
+        O.iterate(it)
+    want = O.image()
+    T.render(1, 3)
+    assert beq(T.read_image(), want)
+    T.close()
+    for var, val in (("PTX_DEBUG_FORCE_SPLIT", "1"), ("PTX_DEBUG_NO_CHUNKS", "1"), ("PTX_DEBUG_WG_PER_CU", "3")):
+        monkeypatch.setenv(var, val)
+        with gpu_product.Tracer(s) as T2:
+            T2.render(1, 3)
+            assert beq(T2.read_image(), want), var
+        monkeypatch.delenv(var)
+
+
 def test_full_size_c4_against_oracle(gpu_product, O):
     """One whole 1920x1080 iteration against the CPU oracle (about 4 s of CPU): identical image."""
     s, T = make_pair(gpu_product, O, "cornellObj.txt", (1920, 1080), 8)
