@@ -807,18 +807,20 @@ __global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const 
 // (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced)
 __global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int nseg, size_t seg_totals,
                         int64_t *last, int64_t *total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t sum = 0;
-        for (int sg = 0; sg < nseg; sg++)
-            for (int b = 0; b < nbounces; b++) {
-                int64_t s = 0;
-                if (!(b == 0 && skip_first))
-                    for (int k = 0; k < nbins; k++) s += totals[seg_totals * sg + (size_t)b * stride + k];
-                if (b < 64) last[b] = s;                 // per-bounce counts of the last iteration of the batch
-                sum += s;
-            }
-        atomicAdd(reinterpret_cast<unsigned long long *>(total), (unsigned long long)sum);
+    // one wave: lane j takes the (segment, bounce) pairs j, j + 64, ...
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    long long sum = 0;
+    for (int k = threadIdx.x; k < nseg * nbounces; k += 64) {
+        const int sg = k / nbounces, b = k - sg * nbounces;
+        long long s = 0;
+        if (!(b == 0 && skip_first))
+            for (int q = 0; q < nbins; q++) s += totals[seg_totals * sg + (size_t)b * stride + q];
+        if (sg == nseg - 1 && b < 64) last[b] = s;      // per-bounce counts of the last iteration of the batch
+        sum += s;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(total), (unsigned long long)sum);
 }
 
 // sendImageToPBO, src/pathtrace.cu:69-89
