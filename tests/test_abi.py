@@ -93,3 +93,21 @@ def test_png_writer_matches_saveimage_semantics(tmp_path):
     # row 0: pixel x=1 (0, .125, clamp(-.5)=0) then x=0 (.25, .5, clamp(1.5)=1)
     assert list(rows[0]) == [0, 31, 0, 63, 127, 255]
     assert list(rows[1]) == [127, 63, 12, 255, 255, 255]
+
+
+def test_headers_are_plain_c_and_link(product, tmp_path):
+    """The boundary is a C ABI: both headers compile as C99 (-pedantic) and a C program links against the library and
+    calls entry points that need no GPU (what a cgo / JNI / ctypes binding would do)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mi355x_pathtracer.h"\n#include "mi355x_stream_compaction.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n    ptx_options opt; ptx_orbit orb; ptx_stats st; (void)orb; (void)st;\n'
+                   '    ptx_default_options(&opt);\n    int in[5] = {1, 0, 2, 0, 3}, out[5];\n'
+                   '    int n = sc_cpu_compact_without_scan(5, out, in);\n'
+                   '    printf("%d %d %d %d\\n", (int)sizeof(ptx_options), opt.antialiasing, opt.cache_first_bounce, n);\n    return 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(product.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lmi355x_pathtracer", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out == ["64", "1", "1", "3"]
