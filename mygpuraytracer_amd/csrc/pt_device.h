@@ -38,7 +38,7 @@ PT_HD float fmin_glm(float x, float y) { return x < y ? x : y; }   // glm min: x
 PT_HD float fmax_glm(float x, float y) { return x > y ? x : y; }   // glm max: x > y ? x : y
 
 // multiplyMV (src/intersections.h:34-36): xyz of mat4*vec4, glm column-major m[c*4+r]
-PT_DEV vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
+PT_HD vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
     vec3 r;
     r.x = (m[0] * v.x + m[4] * v.y) + (m[8] * v.z + m[12] * w);
     r.y = (m[1] * v.x + m[5] * v.y) + (m[9] * v.z + m[13] * w);
@@ -215,7 +215,8 @@ struct DScene {
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
     int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS
-                                        // (pt_lds): tri9 [ntri_lds*9], faces [ntri_lds*15], materials [nmats*11], gtab [ngeoms*40]
+                                        // (pt_lds): tri9 [ntri_lds*9], faces [ntri_lds*15], materials [nmats*11], gtab [ngeoms*40],
+                                        // fnorm [ntri_lds*3], cnorm [ngeoms*18]
     int32_t ntri;
     int32_t ntri_lds;                   // triangles staged with them: ntri, or 0 when the mesh tables stay in global memory
     const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
@@ -225,12 +226,18 @@ struct DScene {
     const BvhQuad *__restrict__ bvh_nodes;          // threaded BVH of the larger meshes (pt_bvh.h), or NULL
     const float *__restrict__ bvh_tris;             // 16 floats per leaf triangle
     const int32_t *__restrict__ bvh_root;           // per geom: root node, -1 = plain loop over its faces
+    const float *__restrict__ fnorm;    // 3 floats per face: its world-space geometric normal, computed at upload with the
+                                        // arithmetic of meshIntersectionTest (src/intersections.h:237-243) -- used when the
+                                        // geom has no bump map; cnorm: 18 floats per geom, the six face normals of a cube
+                                        // (src/intersections.h:86), index (axis * 2 + (sign > 0)) * 3
+    const float *__restrict__ cnorm;
+    uint32_t bump_bits;                 // bit g: mesh g has a bump map (its normals are evaluated per hit, not tabulated)
     int32_t mesh_chunks;                // > 1: no mesh has a BVH and the longest has this many groups of MESH_CHUNK faces:
                                         // tileIntersect spreads every (ray, mesh) pair over that many lanes
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
-PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri_lds * 24 + sc.nmats * 11 + sc.ngeoms * 40 + 3) & ~3; }
+PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri_lds * 27 + sc.nmats * 11 + sc.ngeoms * 58 + 3) & ~3; }
 constexpr int GTAB_WORDS = 40;
 
 // dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]
@@ -246,6 +253,26 @@ __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int n
     for (int k = tid; k < nm; k += nthreads) l[n9 + n15 + k] = m[k];
     const int ng = sc.ngeoms * GTAB_WORDS;
     for (int k = tid; k < ng; k += nthreads) l[n9 + n15 + nm + k] = sc.gtab[k];
+    const int nf = sc.ntri_lds * 3, nc = sc.ngeoms * 18;
+    for (int k = tid; k < nf; k += nthreads) l[n9 + n15 + nm + ng + k] = sc.fnorm[k];
+    for (int k = tid; k < nc; k += nthreads) l[n9 + n15 + nm + ng + nf + k] = sc.cnorm[k];
+}
+// precomputed normals: face `face` (global index) of the meshes / side `side` of cube `g`
+PT_DEV vec3 faceNormalTab(const DScene &sc, int face) {
+    if (sc.tri_lds && sc.ntri_lds) {
+        const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11 + sc.ngeoms * GTAB_WORDS + face * 3;
+        return V3(l[0], l[1], l[2]);
+    }
+    const float *gp = sc.fnorm + (size_t)face * 3;
+    return V3(gp[0], gp[1], gp[2]);
+}
+PT_DEV vec3 cubeNormalTab(const DScene &sc, int g, int side) {
+    if (sc.tri_lds) {
+        const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 27 + sc.nmats * 11 + sc.ngeoms * GTAB_WORDS + g * 18 + side * 3;
+        return V3(l[0], l[1], l[2]);
+    }
+    const float *gp = sc.cnorm + (size_t)g * 18 + side * 3;
+    return V3(gp[0], gp[1], gp[2]);
 }
 
 // struct Material of material `id` (per-lane id: from LDS when staged, else global memory)
@@ -369,7 +396,7 @@ PT_DEV uint32_t texel(const DScene &sc, const DTex &t, int pixelID, int c) {
     return (uint32_t)sc.texels[t.off + (uint64_t)idx];
 }
 
-PT_DEV vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
+PT_HD vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
 
 // One triangle of glm::intersectRayTriangle (glm/gtx/intersect.inl:37-74, single sided: a < epsilon => miss) with
 // e1 = v1 - v0 and e2 = v2 - v0 taken from the upload-time table.
@@ -602,7 +629,7 @@ PT_DEV void intersectScene(const DScene &sc, Ray ray, Hit &h) {
 // worked off by dense waves.
 
 // xyz of mat4*vec4 for a matrix stored as 3 rows of 4 (same products and sums as multiplyMV)
-PT_DEV vec3 mulRows(const float *r, vec3 v, float w) {
+PT_HD vec3 mulRows(const float *r, vec3 v, float w) {
     vec3 o;
     o.x = (r[0] * v.x + r[1] * v.y) + (r[2] * v.z + r[3] * w);
     o.y = (r[4] * v.x + r[5] * v.y) + (r[6] * v.z + r[7] * w);
@@ -772,17 +799,20 @@ PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long ke
             c.v = (w * faceWord(sc, f, 4) + b0 * faceWord(sc, f, 9)) + b1 * faceWord(sc, f, 14);
         }
         h.u = c.u; h.v = c.v;
-        vec3 geoN;
-        h.n = meshNormal(sc, geom, c, geoN);
+        if ((sc.bump_bits >> g) & 1u) {
+            vec3 geoN;
+            h.n = meshNormal(sc, geom, c, geoN);
+        } else {            // no bump map: the face's normal was computed at upload (same arithmetic, same bits)
+            h.n = faceNormalTab(sc, __float_as_int(G[38]) + c.face);
+        }
     } else {
         float invT[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
-        if (type == G_CUBE) {
+        if (type == G_CUBE) {   // one of six normals per cube, computed at upload (normalize(invTranspose * +-e_axis))
             const int axis = (int)(aux & 3u) - 1;
-            const float sgn = (aux & 4u) ? 1.f : -1.f;
-            vec3 n = V3(axis == 0 ? sgn : 0.f, axis == 1 ? sgn : 0.f, axis == 2 ? sgn : 0.f);
-            h.n = normalize(mulRows(invT, n, 0.0f));
+            if (axis >= 0) h.n = cubeNormalTab(sc, g, axis * 2 + ((aux & 4u) ? 1 : 0));
+            else h.n = normalize(mulRows(invT, V3(0.f, 0.f, 0.f), 0.0f));    // no axis recorded (NaN inputs): the reference's zero vector
         } else {            // sphere: the object-space hit point is recomputed (same arithmetic as in primKey)
             float inv[12];
 #pragma unroll

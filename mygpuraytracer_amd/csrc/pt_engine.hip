@@ -965,6 +965,8 @@ struct ptx_tracer {
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr;   // pt_bvh.h (NULL: no mesh has one)
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
     int mesh_chunks = 1;                                 // see DScene::mesh_chunks
+    float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
+    uint32_t bump_bits = 0;
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
     unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
     size_t seg_items = 0;
@@ -1001,6 +1003,7 @@ struct ptx_tracer {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
         s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
+        s.fnorm = d_fnorm; s.cnorm = d_cnorm; s.bump_bits = bump_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
     }
@@ -1062,7 +1065,7 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
@@ -1090,7 +1093,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const size_t seg0 = (size_t)lane * t->kmax;
     const int nb = t->nbins;
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
-    const int triWords = t->tri_lds ? ((ntri_lds * 24 + t->nmats * 11 + t->ngeoms * 40 + 3) & ~3) : 0;
+    const int triWords = t->tri_lds ? ((ntri_lds * 27 + t->nmats * 11 + t->ngeoms * 58 + 3) & ~3) : 0;
     const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
@@ -1371,8 +1374,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     }
     // materials and geom tables go to LDS; the triangle tables join them when that leaves room for at least 2 workgroups
     // per CU (160 KB LDS, ~19 KB of sort buffers) -- otherwise they are read from global memory (L2-resident)
-    t->tri_lds = (((size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
-    t->ntri_lds = (t->tri_lds && ((size_t)t->ntri * 24 + (size_t)nmaterials * 11 + (size_t)ngeoms * 40) * 4 <= 56 * 1024) ? t->ntri : 0;
+    t->tri_lds = (((size_t)nmaterials * 11 + (size_t)ngeoms * 58) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
+    t->ntri_lds = (t->tri_lds && ((size_t)t->ntri * 27 + (size_t)nmaterials * 11 + (size_t)ngeoms * 58) * 4 <= 56 * 1024) ? t->ntri : 0;
     // per-geom table for the per-lane gathers (rows 0-2 of the three matrices) and conservative world boxes
     std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 8, 0.f);
     for (int i = 0; i < ngeoms; i++) {
@@ -1394,6 +1397,39 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         }
     }
     t->cull = (t->tri_lds && ngeoms >= 1 && ngeoms <= 32 && !opt.no_cull) ? 1 : 0;
+    {   // normals that do not depend on the ray, computed once with the device's own functions (compiled for the host with
+        // the same flags: no contraction, IEEE divide and square root), so the kernels read what they would have computed
+        std::vector<float> hfn((size_t)std::max(t->ntri, 1) * 3, 0.f), hcn((size_t)std::max(ngeoms, 1) * 18, 0.f);
+        for (int i = 0; i < ngeoms; i++) {
+            const DGeom &d = hg[i];
+            if (d.type == G_OBJ) {
+                if (d.tex[3].ch && i < 32) t->bump_bits |= 1u << i;
+                for (int j = 0; j < d.faceCount; j++) {          // meshIntersectionTest, src/intersections.h:237-243
+                    const float *tri = &hfaces[((size_t)d.faceStart + j) * 15];
+                    const vec3 e1 = sub(ld3(tri + 5), ld3(tri)), e2 = sub(ld3(tri + 10), ld3(tri));
+                    const vec3 objN = normalize(cross(e1, e2));
+                    const vec3 n = normalize(multiplyMV(d.invT, objN, 0.f));
+                    float *o = &hfn[((size_t)d.faceStart + j) * 3];
+                    o[0] = n.x; o[1] = n.y; o[2] = n.z;
+                }
+            } else if (d.type == G_CUBE) {                       // boxIntersectionTest, src/intersections.h:86
+                const float *invT = &hgtab[(size_t)i * 40 + 24];
+                for (int side = 0; side < 6; side++) {
+                    const int axis = side >> 1;
+                    const float sgn = (side & 1) ? 1.f : -1.f;
+                    const vec3 e = V3(axis == 0 ? sgn : 0.f, axis == 1 ? sgn : 0.f, axis == 2 ? sgn : 0.f);
+                    const vec3 n = normalize(mulRows(invT, e, 0.0f));
+                    float *o = &hcn[(size_t)i * 18 + side * 3];
+                    o[0] = n.x; o[1] = n.y; o[2] = n.z;
+                }
+            }
+        }
+        if (ngeoms > 32) t->bump_bits = 0xffffffffu;          // (no per-geom bit beyond 32 geoms: such scenes do not take the tile path)
+        HC(hipMalloc(&t->d_fnorm, sizeof(float) * hfn.size()));
+        HC(hipMemcpy(t->d_fnorm, hfn.data(), sizeof(float) * hfn.size(), hipMemcpyHostToDevice));
+        HC(hipMalloc(&t->d_cnorm, sizeof(float) * hcn.size()));
+        HC(hipMemcpy(t->d_cnorm, hcn.data(), sizeof(float) * hcn.size(), hipMemcpyHostToDevice));
+    }
     if (hfaces.empty()) hfaces.resize(15, 0.f);
     if (htex.empty()) htex.resize(16, 0);
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
