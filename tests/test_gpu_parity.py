@@ -596,3 +596,38 @@ def test_edge_many_materials(gpu_product, O, tmp_path):
     _vs_oracle(gpu_product, O, s, iters=4)
     _vs_oracle(gpu_product, O, s, iters=4, batch=1)
     _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1, antialiasing=0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes_on_the_tile_path(gpu_product, O, tmp_path, seed):
+    """Fuzz of the fast path (<= 32 geoms: candidate masks, pooled pairs, tabulated normals, chunked small meshes, BVH +
+    split mesh search when the stand-in ship is in): random counts of arbitrarily rotated and non-uniformly scaled cubes,
+    spheres and meshes, every material class, inside a lit box.  Image and rays per bounce equal the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    mats = [(1, 1, 1, 0, 0, 0, 0, 0, 0, 5), (.9, .9, .9, 0, 0, 0, 0, 0, 0, 0), (.8, .3, .3, 0, 0, 0, 0, 0, 0, 0),
+            (.3, .8, .3, 0, 0, 0, 0, 0, 0, 0), (.95, .95, .95, .95, .95, .95, 1, 0, 0, 0), (.95, .95, .95, .8, .85, .95, 0, 1, 1.5, 0),
+            (.3, .4, .9, 0, 0, 0, 0, 0, 0, 0)]
+    text = "".join(MAT % ((m,) + mats[m]) for m in range(len(mats))) + CAMERA_BLOCK
+    objs = ["cube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 4 .3 4", "cube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 11 .01 11",
+            "cube\nmaterial 1\nTRANS 0 10 0\nROTAT 0 0 90\nSCALE .01 11 11", "cube\nmaterial 1\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 11 11",
+            "cube\nmaterial 2\nTRANS -5 5 0\nROTAT 0 0 0\nSCALE .01 11 11", "cube\nmaterial 3\nTRANS 5 5 0\nROTAT 0 0 0\nSCALE .01 11 11"]
+    n_extra = int(rng.integers(3, 20))
+    ship_at = int(rng.integers(0, n_extra)) if seed % 2 == 0 else -1
+    for k in range(n_extra):
+        pos = rng.uniform([-3.5, 1.0, -3.5], [3.5, 8.0, 3.0])
+        rot = rng.uniform(-180, 180, 3)
+        sc = rng.uniform(0.5, 2.2, 3)
+        kind = int(rng.integers(0, 4))
+        if k == ship_at:
+            head = "obj\n../models/standin_ship.obj"
+        elif kind == 0:
+            head = "obj\n../models/cube.obj"
+        else:
+            head = ("sphere" if kind == 1 else "cube") + "\nmaterial %d" % int(rng.integers(1, len(mats)))
+        objs.append(head + "\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g" % (tuple(pos) + tuple(rot) + tuple(sc)))
+    text += "".join("OBJECT %d\n%s\n\n" % (i, o) for i, o in enumerate(objs))
+    s = _scene_from_text(gpu_product, text, tmp_path, res=(112, 80), depth=7)
+    assert s.num_geoms == len(objs) <= 32
+    _vs_oracle(gpu_product, O, s, iters=3)
+    _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1)
+    _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
