@@ -19,8 +19,13 @@
 //                 survivors (including the ones that were dropped) is carried as its stream index, because
 //                 that index seeds the shading RNG [:373] and must be the reference's.
 //  * The live count never visits the host: kernels read it from device memory and use grid-stride tile loops,
-//    so an iteration is a fixed sequence of launches on one stream.
-//  * Scene data (<= a few KB) is read with wave-uniform indices, i.e. through the scalar cache into SGPRs.
+//    so a batch of iterations is a fixed sequence of launches; K iterations ride in every launch as segments
+//    (blockIdx.y), and two such batches are in flight on two streams so that k_move (HBM) overlaps k_bounce (VALU).
+//  * Intersection is tile-cooperative (tileIntersect): candidate masks from conservative world boxes, the (ray, geom)
+//    pairs of a 256-path tile pooled in LDS and worked off by dense waves with a 64-bit LDS minimum per ray.  Scenes
+//    with BVH meshes run the mesh search as a kernel of its own (k_mesh) between two halves of k_bounce.
+//  * Scene tables (materials, per-geom matrices, small meshes' triangles, tabulated normals) are staged in LDS; the
+//    world boxes are read through the scalar cache.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -992,7 +997,7 @@ struct ptx_tracer {
     // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
     bool ktiming = false;
     std::vector<hipEvent_t> kev;                         // pairs (start, stop)
-    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 (unused), 3 k_move
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh, 3 k_move
     size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;
