@@ -1226,7 +1226,6 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx(), cb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg(), cb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
-            const size_t fstride = (first && cache_on) ? (size_t)t->cap : t->field_stride;
             for (int f = 0; f < SOA_FLOATS; f++)
                 HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.field(f),
                                         sizeof(float) * (size_t)t->cap, hipMemcpyDeviceToDevice, stream));

@@ -11,8 +11,9 @@
 //   * OBJ/MTL parsing is a small own parser (the reference vendors tinyobjloader 2.0): v / vt / f records,
 //     triangles and quads (quads split along the shorter diagonal, ties -> [0,1,3],[1,2,3], as
 //     tiny_obj_loader.h:1511-1553 does); polygons with more than 4 corners are rejected;
-//   * textures are read from binary PPM (P6) files, flipped vertically like stbi_set_flip_vertically_on_load
-//     (src/scene.cpp:133); any other format counts as "failed to load" => empty texture, as in the reference.
+//   * textures are read from binary PPM (P6) and PNG files (pt_png.h), flipped vertically like
+//     stbi_set_flip_vertically_on_load (src/scene.cpp:133); any other format (JPEG, ...) counts as "failed to load"
+//     => empty texture, the reference's own fallback.
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@
 
 #include "../../include/mi355x_pathtracer.h"
 #include "pt_hostmath.h"
+#include "pt_png.h"
 
 // the error string lives in pt_engine.hip next to ptx_last_error()
 extern "C" void ptx_internal_set_error(const char *msg);
@@ -130,6 +132,15 @@ bool load_ppm_flipped(const std::string &path, int &w, int &h, int &ch, std::vec
     pixels.resize(need);
     for (int y = 0; y < h; y++) memcpy(&pixels[(size_t)(h - 1 - y) * w * 3], &d[p + (size_t)y * w * 3], (size_t)w * 3);
     return true;
+}
+
+// a texture file as stbi_load(name, &w, &h, &n, 0) with the vertical flip would deliver it: binary PPM or PNG (pt_png.h);
+// anything else (JPEG, ...) is "failed to load" => empty texture, the reference's own fallback (src/scene.cpp:152-156)
+bool load_texture_flipped(const std::string &path, int &w, int &h, int &ch, std::vector<uint8_t> &pixels) {
+    if (load_ppm_flipped(path, w, h, ch, pixels)) return true;
+    std::string d;
+    if (!read_file(path, d)) return false;
+    return ptpng::load_png_flipped(d, w, h, ch, pixels);
 }
 
 struct MtlInfo {
@@ -250,7 +261,7 @@ int load_obj(const std::string &base_dir, const std::string &objpath, ptx_scene 
         slots[k]->width = slots[k]->height = slots[k]->channels = 0; slots[k]->image = nullptr;
         if (names[k]->empty()) continue;
         int w, h, ch;
-        if (load_ppm_flipped(join_path(base_dir, normalise_separators(*names[k])), w, h, ch, tex[k])) {
+        if (load_texture_flipped(join_path(base_dir, normalise_separators(*names[k])), w, h, ch, tex[k])) {
             slots[k]->width = w; slots[k]->height = h; slots[k]->channels = ch;
         }
     }

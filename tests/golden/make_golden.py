@@ -117,6 +117,35 @@ def random_rays(rng, n, centre, radius):
     return np.concatenate([o, d], 1).astype(np.float32)
 
 
+def png_textures(R):
+    """PNG maps through the reference's loader (stb_image, vertical flip): the files of tests/pngcases.py and the texels
+    the reference hands to pathtraceInit for each of them -> png_textures.npz (file bytes + expected texels)."""
+    import tempfile
+    import pngcases
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        for d in ("scenes", "models/materials", "textures"):
+            os.makedirs(os.path.join(root, d))
+        with open(os.path.join(root, "models", "q.obj"), "w") as f:
+            f.write("mtllib q.mtl\nv 0 0 0\nv 3 0 0\nv 3 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\n")
+        with open(os.path.join(root, "models", "materials", "q.mtl"), "w") as f:      # all four maps: the reference indexes
+            f.write("newmtl a\nKd .1 .2 .3\nKs .4 .5 .6\nNi 1.5\n" +                    # its texture vectors by geom
+                    "".join("map_%s ../textures/t.png\n" % k for k in ("Kd", "Ks", "Ke", "Bump")))
+        text = open(os.path.join(REPO_SCENES, "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/q.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n"
+        with open(os.path.join(root, "scenes", "s.txt"), "w") as f:
+            f.write(text)
+        for name, png in pngcases.cases():
+            with open(os.path.join(root, "textures", "t.png"), "wb") as f:
+                f.write(png)
+            R.load(os.path.join(root, "scenes", "s.txt"), cwd=os.path.join(root, "scenes"))
+            tex = R.dump()["textures"]
+            out["file_" + name] = np.frombuffer(png, np.uint8)
+            out["texels_" + name] = tex[(1, 0)]
+            assert all(np.array_equal(tex[(1, 0)], tex[(1, k)]) for k in (1, 2, 3))
+    np.savez_compressed(os.path.join(HERE, "png_textures.npz"), **out)
+    print("png_textures.npz:", len(out) // 2, "files")
+
+
 def main():
     so = build_ref()
     if not so:
@@ -268,6 +297,7 @@ def main():
         full[tag + "_image_rowsum"] = img.reshape(res[1], res[0], 3).sum(axis=(1, 2), dtype=np.float64).astype(np.float64)
         print(tag, R.live_counts().tolist(), img.mean(dtype=np.float64))
     np.savez_compressed(os.path.join(HERE, "fullres_counts.npz"), **full)
+    png_textures(R)
     print("golden fixtures written to", HERE)
 
 

@@ -118,3 +118,48 @@ def test_ppm_textures_and_quad_split(product, tmp_path):
     assert np.allclose(d["materials"][1], [.1, .2, .3, 0, .4, .5, .6, 0, 0, 1.5, 0])
     assert set(d["textures"]) == {(1, 0), (1, 2)}
     assert np.array_equal(d["textures"][(1, 0)], img[::-1])
+
+
+def _png_scene(tmp_path, png_bytes):
+    for d in ("scenes", "models/materials", "textures"):
+        os.makedirs(tmp_path / d, exist_ok=True)
+    (tmp_path / "textures" / "t.png").write_bytes(png_bytes)
+    (tmp_path / "models" / "materials" / "q.mtl").write_text("newmtl a\nKd .1 .2 .3\nKs .4 .5 .6\nNi 1.5\nmap_Kd ../textures/t.png\nmap_Bump ..\\textures\\t.png\n")
+    (tmp_path / "models" / "q.obj").write_text("mtllib q.mtl\nv 0 0 0\nv 3 0 0\nv 3 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\n")
+    text = open(os.path.join(ROOT, "scenes", "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/q.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n"
+    (tmp_path / "scenes" / "s.txt").write_text(text)
+    return str(tmp_path / "scenes" / "s.txt")
+
+
+def test_png_textures_match_the_reference_loader(product, tmp_path):
+    """PNG maps (csrc/pt_png.h) against what the reference's loader -- stb_image with the vertical flip -- made of the same
+    files (tests/golden/png_textures.npz, generated by make_golden.py from tests/pngcases.py): every colour type and bit
+    depth, all five filters, Adam7, palette and colour-key transparency, stored and dynamic-Huffman streams."""
+    import pngcases
+    g = golden("png_textures.npz")
+    names = [n for n, _ in pngcases.cases()]
+    assert len(names) == 17 and all("file_" + n in g.files for n in names)
+    for name, png in pngcases.cases():
+        assert png == bytes(g["file_" + name])                       # the committed bytes are what the generator writes
+        d = product.Scene(_png_scene(tmp_path, png)).dump()
+        want = g["texels_" + name]
+        got = d["textures"][(1, 0)]
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        assert np.array_equal(d["textures"][(1, 3)], want)             # map_Bump with Windows separators
+
+
+def test_broken_png_is_a_failed_load_not_a_crash(product, tmp_path):
+    """Truncated, corrupted and non-PNG files give an empty texture, the reference's own outcome for a failed stbi_load."""
+    import pngcases
+    png = dict(pngcases.cases())["rgb8"]
+    rng = np.random.default_rng(3)
+    variants = [png[:40], png[:-20], b"\x89PNG\r\n\x1a\n" + b"\0" * 64, b"JFIF" * 10, b""]
+    for k in range(40):                                                # random byte flips anywhere in the file
+        b = bytearray(png)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
+        variants.append(bytes(b))
+    for v in variants:
+        d = product.Scene(_png_scene(tmp_path, v)).dump()             # must not crash; a texture, if any, has sane dimensions
+        t = d["textures"].get((1, 0))
+        assert t is None or (t.ndim == 3 and t.shape[2] in (1, 2, 3, 4) and t.size <= 1 << 20)
