@@ -9,7 +9,7 @@
 //   16 bits per sample                    -> the high byte        1/2/4-bit grey -> scaled by 255 / 85 / 17
 //   Adam7 interlace                       -> de-interlaced         CRCs and the zlib Adler-32 are not checked (stb does not)
 // Rows come out bottom-up (the vertical flip).  tests/test_loader.py pins this against the reference's own loader
-// (oracle/_ref) on files written by PIL.
+// (oracle/_ref) on the hand-written files of tests/pngcases.py.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -124,6 +124,7 @@ inline bool inflate_zlib(const std::vector<uint8_t> &z, std::vector<uint8_t> &ou
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) return false;
+                if (out.size() > expect + (1u << 20)) return false;      // far more data than the picture needs: not a texture
                 if (sym < 256) out.push_back((uint8_t)sym);
                 else if (sym == 256) break;
                 else {
