@@ -631,3 +631,35 @@ def test_random_scenes_on_the_tile_path(gpu_product, O, tmp_path, seed):
     _vs_oracle(gpu_product, O, s, iters=3)
     _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1)
     _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
+
+
+def test_png_rgba_maps_render_like_the_oracle(gpu_product, O, tmp_path):
+    """The stand-in ship with its four maps as 4-channel PNGs (texel stride 4, alpha ignored as in the reference's
+    image[(..) * channels + c]): loader -> HIP tracer equals loader -> oracle, and equals the PPM version of the scene
+    because the colour bytes are the same."""
+    import shutil
+    import pngcases
+    for d in ("scenes", "models/materials", "textures"):
+        os.makedirs(tmp_path / d)
+    shutil.copy(os.path.join(ROOT, "models", "standin_ship.obj"), tmp_path / "models")
+    mtl = open(os.path.join(ROOT, "models", "materials", "standin_ship.mtl")).read().replace(".ppm", ".png")
+    (tmp_path / "models" / "materials" / "standin_ship.mtl").write_text(mtl)
+    rng = np.random.default_rng(4)
+    for k in ("kd", "ks", "ke", "bump"):
+        raw = open(os.path.join(ROOT, "textures", "standin_%s.ppm" % k), "rb").read()
+        head, w, h, mx, body = raw.split(b"\n", 3)[0], *raw.split(b"\n", 3)[1].split(), raw.split(b"\n", 3)[2], raw.split(b"\n", 3)[3]
+        w, h = int(w), int(h)
+        rgb = np.frombuffer(body, np.uint8).reshape(h, w, 3)
+        rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+        (tmp_path / "textures" / ("standin_%s.png" % k)).write_bytes(pngcases.make_png(w, h, 6, 8, rgba.astype(int), rng=rng))
+    text = open(os.path.join(ROOT, "scenes", "cornellSpaceship.txt")).read()
+    (tmp_path / "scenes" / "ship.txt").write_text(text)
+    s = gpu_product.Scene(str(tmp_path / "scenes" / "ship.txt"), res=(96, 54), depth=8)
+    s.apply_runcuda_camera()
+    assert all(t.shape[2] == 4 for t in s.dump()["textures"].values()) and len(s.dump()["textures"]) == 4
+    img = _vs_oracle(gpu_product, O, s, iters=3)
+    s3 = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship.txt"), res=(96, 54), depth=8)
+    s3.apply_runcuda_camera()
+    with gpu_product.Tracer(s3) as T:
+        T.render(1, 3)
+        assert beq(T.read_image(), img)
