@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""The C5-shaped run alone (for rocprofv3 --kernel-trace --stats): 3840x2160, depth 8, AA + DoF, 20448-triangle stand-in,
+64 iterations, one launch set at a time so that kernel durations are the kernels' own."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mygpuraytracer_amd as pt
+from conftest import ensure_standin_assets
+ensure_standin_assets()
+s = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=(3840, 2160), depth=8); s.apply_runcuda_camera()
+with pt.Tracer(s, depth_of_field=1, lanes=1) as T:
+    T.render(1, 64); T.synchronize()
+    print("loop ms per iteration", T.last_loop_ms() / 64)
