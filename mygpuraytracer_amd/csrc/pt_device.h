@@ -204,7 +204,10 @@ struct alignas(16) BvhQuad { float x, y, z; int32_t w; };
 #define PT_MESH_CHUNK 4
 #endif
 constexpr int MESH_CHUNK = PT_MESH_CHUNK;            // faces per lane when a small mesh's loop is spread over lanes
-constexpr int BVH_LEAF_MAX = 4;
+#ifndef PT_BVH_LEAF
+#define PT_BVH_LEAF 2
+#endif
+constexpr int BVH_LEAF_MAX = PT_BVH_LEAF;
 constexpr int BVH_MIN_FACES = 24;        // meshes smaller than this keep the plain loop
 struct DScene {
     const DGeom *__restrict__ geoms;
