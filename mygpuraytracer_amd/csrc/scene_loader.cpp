@@ -11,9 +11,9 @@
 //   * OBJ/MTL parsing is a small own parser (the reference vendors tinyobjloader 2.0): v / vt / f records,
 //     triangles and quads (quads split along the shorter diagonal, ties -> [0,1,3],[1,2,3], as
 //     tiny_obj_loader.h:1511-1553 does); polygons with more than 4 corners are rejected;
-//   * textures are read from binary PPM (P6) and PNG files (pt_png.h), flipped vertically like
-//     stbi_set_flip_vertically_on_load (src/scene.cpp:133); any other format (JPEG, ...) counts as "failed to load"
-//     => empty texture, the reference's own fallback.
+//   * textures are read from binary PPM (P6), PNG (pt_png.h) and JPEG (pt_jpeg.h) files, flipped vertically like
+//     stbi_set_flip_vertically_on_load (src/scene.cpp:133); any other format counts as "failed to load" => empty
+//     texture, the reference's own fallback.
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +26,7 @@
 #include "../../include/mi355x_pathtracer.h"
 #include "pt_hostmath.h"
 #include "pt_png.h"
+#include "pt_jpeg.h"
 
 // the error string lives in pt_engine.hip next to ptx_last_error()
 extern "C" void ptx_internal_set_error(const char *msg);
@@ -134,13 +135,14 @@ bool load_ppm_flipped(const std::string &path, int &w, int &h, int &ch, std::vec
     return true;
 }
 
-// a texture file as stbi_load(name, &w, &h, &n, 0) with the vertical flip would deliver it: binary PPM or PNG (pt_png.h);
-// anything else (JPEG, ...) is "failed to load" => empty texture, the reference's own fallback (src/scene.cpp:152-156)
+// a texture file as stbi_load(name, &w, &h, &n, 0) with the vertical flip would deliver it: binary PPM, PNG (pt_png.h) or
+// JPEG (pt_jpeg.h); anything else is "failed to load" => empty texture, the reference's own fallback (src/scene.cpp:152-156)
 bool load_texture_flipped(const std::string &path, int &w, int &h, int &ch, std::vector<uint8_t> &pixels) {
     if (load_ppm_flipped(path, w, h, ch, pixels)) return true;
     std::string d;
     if (!read_file(path, d)) return false;
-    return ptpng::load_png_flipped(d, w, h, ch, pixels);
+    if (ptpng::load_png_flipped(d, w, h, ch, pixels)) return true;
+    return ptjpeg::load_jpeg_flipped(d, w, h, ch, pixels);
 }
 
 struct MtlInfo {

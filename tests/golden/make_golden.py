@@ -146,6 +146,34 @@ def png_textures(R):
     print("png_textures.npz:", len(out) // 2, "files")
 
 
+def jpeg_textures(R):
+    """JPEG maps through the reference's loader (stb_image v2.27, vertical flip): the files of tests/jpegcases.py and the texels
+    the reference hands to pathtraceInit for each of them -> jpeg_textures.npz (file bytes + expected texels; None = failed load)."""
+    import tempfile
+    import jpegcases
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        for d in ("scenes", "models/materials", "textures"):
+            os.makedirs(os.path.join(root, d))
+        with open(os.path.join(root, "models", "q.obj"), "w") as f:
+            f.write("mtllib q.mtl\nv 0 0 0\nv 3 0 0\nv 3 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\n")
+        with open(os.path.join(root, "models", "materials", "q.mtl"), "w") as f:
+            f.write("newmtl a\nKd .1 .2 .3\nKs .4 .5 .6\nNi 1.5\n" + "".join("map_%s ../textures/t.jpg\n" % k for k in ("Kd", "Ks", "Ke", "Bump")))
+        text = open(os.path.join(REPO_SCENES, "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/q.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n"
+        with open(os.path.join(root, "scenes", "s.txt"), "w") as f:
+            f.write(text)
+        for name, jpg in jpegcases.cases():
+            with open(os.path.join(root, "textures", "t.jpg"), "wb") as f:
+                f.write(jpg)
+            R.load(os.path.join(root, "scenes", "s.txt"), cwd=os.path.join(root, "scenes"))
+            tex = R.dump()["textures"].get((1, 0))
+            out["file_" + name] = np.frombuffer(jpg, np.uint8)
+            out["texels_" + name] = tex if tex is not None else np.zeros((0, 0, 0), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "jpeg_textures.npz"), **out)
+    import PIL
+    print("jpeg_textures.npz:", len(out) // 2, "files (written with PIL %s)" % PIL.__version__)
+
+
 def main():
     so = build_ref()
     if not so:
@@ -298,6 +326,7 @@ def main():
         print(tag, R.live_counts().tolist(), img.mean(dtype=np.float64))
     np.savez_compressed(os.path.join(HERE, "fullres_counts.npz"), **full)
     png_textures(R)
+    jpeg_textures(R)
     print("golden fixtures written to", HERE)
 
 

@@ -163,3 +163,54 @@ def test_broken_png_is_a_failed_load_not_a_crash(product, tmp_path):
         d = product.Scene(_png_scene(tmp_path, v)).dump()             # must not crash; a texture, if any, has sane dimensions
         t = d["textures"].get((1, 0))
         assert t is None or (t.ndim == 3 and t.shape[2] in (1, 2, 3, 4) and t.size <= 1 << 20)
+
+
+def _jpeg_scene(tmp_path, jpg_bytes):
+    for d in ("scenes", "models/materials", "textures"):
+        os.makedirs(tmp_path / d, exist_ok=True)
+    (tmp_path / "textures" / "t.jpg").write_bytes(jpg_bytes)
+    (tmp_path / "models" / "materials" / "q.mtl").write_text("newmtl a\nKd .1 .2 .3\nKs .4 .5 .6\nNi 1.5\nmap_Kd ../textures/t.jpg\n")
+    (tmp_path / "models" / "q.obj").write_text("mtllib q.mtl\nv 0 0 0\nv 3 0 0\nv 3 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\n")
+    text = open(os.path.join(ROOT, "scenes", "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/q.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n"
+    (tmp_path / "scenes" / "s.txt").write_text(text)
+    return str(tmp_path / "scenes" / "s.txt")
+
+
+def test_jpeg_textures_match_the_reference_loader(product, tmp_path):
+    """JPEG maps (csrc/pt_jpeg.h) against what the reference's loader -- stb_image v2.27 with the vertical flip -- made of
+    the same bytes (tests/golden/jpeg_textures.npz, from tests/jpegcases.py through make_golden.py): JPEG is lossy, so the
+    decoder's integer IDCT, chroma upsampling and fixed-point colour conversion have to be the reference's for the texels
+    to agree bit for bit.  44 files: baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1 / 4:4:0, optimised tables,
+    restart intervals, 16-bit quantisation tables, greyscale, CMYK, untransformed RGB, sizes down to one pixel wide,
+    entropy data that ends early."""
+    g = golden("jpeg_textures.npz")
+    names = [f[5:] for f in g.files if f.startswith("file_")]
+    assert len(names) == 44
+    kinds = set()
+    for name in names:
+        d = product.Scene(_jpeg_scene(tmp_path, bytes(g["file_" + name]))).dump()
+        want = g["texels_" + name]
+        got = d["textures"].get((1, 0))
+        if want.size == 0:
+            assert got is None, name                                  # the reference failed to load it
+            kinds.add("fail")
+        else:
+            assert got is not None and got.shape == want.shape and np.array_equal(got, want), name
+            kinds.add(want.shape[2])
+    assert {1, 3} <= kinds
+
+
+def test_broken_jpeg_is_a_failed_load_not_a_crash(product, tmp_path):
+    g = golden("jpeg_textures.npz")
+    jpg = bytes(g["file_blobs_prog420"])
+    rng = np.random.default_rng(8)
+    variants = [jpg[:30], jpg[:-2], b"\xff\xd8\xff", b"\xff\xd8" + b"\0" * 50]
+    for k in range(60):
+        b = bytearray(jpg)
+        for _ in range(int(rng.integers(1, 5))):
+            b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+        variants.append(bytes(b))
+    for v in variants:
+        d = product.Scene(_jpeg_scene(tmp_path, v)).dump()
+        t = d["textures"].get((1, 0))
+        assert t is None or (t.ndim == 3 and t.shape[2] in (1, 3) and t.size <= 1 << 22)
