@@ -10,7 +10,7 @@
 //     reference's four scene-wide vectors that fall out of step with geoms (src/scene.cpp:138-218);
 //   * OBJ/MTL parsing is a small own parser (the reference vendors tinyobjloader 2.0): v / vt / f records,
 //     triangles and quads (quads split along the shorter diagonal, ties -> [0,1,3],[1,2,3], as
-//     tiny_obj_loader.h:1511-1553 does); polygons with more than 4 corners are rejected;
+//     tiny_obj_loader.h:1511-1553 does); polygons with more corners by its ear clipping (triangulate_ngon below);
 //   * textures are read from binary PPM (P6), PNG (pt_png.h) and JPEG (pt_jpeg.h) files, flipped vertically like
 //     stbi_set_flip_vertically_on_load (src/scene.cpp:133); any other format counts as "failed to load" => empty
 //     texture, the reference's own fallback.
@@ -204,6 +204,74 @@ bool parse_face_corner(const std::string &tok, int nv, int nvt, ObjIndex &out) {
     return out.v >= 0 && out.v < nv;
 }
 
+// point-in-polygon by crossing number, as tiny_obj_loader.h:1414-1426 evaluates it (float arithmetic, same expression)
+bool pnpoly3(const float *vertx, const float *verty, float testx, float testy) {
+    bool c = false;
+    for (int i = 0, j = 2; i < 3; j = i++)
+        if (((verty[i] > testy) != (verty[j] > testy)) &&
+            (testx < (vertx[j] - vertx[i]) * (testy - verty[i]) / (verty[j] - verty[i]) + vertx[i]))
+            c = !c;
+    return c;
+}
+
+// Polygons with more than four corners, cut into triangles the way tinyobjloader's built-in ear clipping does
+// (tiny_obj_loader.h:1566-1852): project on the two axes chosen from the first non-degenerate corner, walk a candidate
+// corner around the polygon, emit it as an ear unless it turns the wrong way ("cross * area < 0", where area is the
+// quirky 0.5 * (x0 * y1 - y0 * x1) of the candidate's first two vertices) or another vertex lies inside it, remove its
+// middle vertex; give up after a full round without progress, and emit what is left if it is a triangle.
+template <class PushTri>
+void triangulate_ngon(const std::vector<ObjIndex> &face, const std::vector<float> &v, PushTri push_tri) {
+    size_t npolys = face.size();
+    size_t axes[2] = {1, 2};
+    for (size_t k = 0; k < npolys; ++k) {
+        const float *a = &v[(size_t)face[(k + 0) % npolys].v * 3], *b = &v[(size_t)face[(k + 1) % npolys].v * 3],
+                    *c = &v[(size_t)face[(k + 2) % npolys].v * 3];
+        const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+        const float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+        const float cx = fabsf(e0y * e1z - e0z * e1y), cy = fabsf(e0z * e1x - e0x * e1z), cz = fabsf(e0x * e1y - e0y * e1x);
+        const float epsilon = 1.1920928955078125e-07f;
+        if (cx > epsilon || cy > epsilon || cz > epsilon) {
+            if (!(cx > cy && cx > cz)) {
+                axes[0] = 0;
+                if (cz > cx && cz > cy) axes[1] = 1;
+            }
+            break;
+        }
+    }
+    std::vector<ObjIndex> rem = face;
+    size_t guess_vert = 0;
+    size_t remainingIterations = face.size(), previousRemainingVertices = rem.size();
+    while (rem.size() > 3 && remainingIterations > 0) {
+        npolys = rem.size();
+        if (guess_vert >= npolys) guess_vert -= npolys;
+        if (previousRemainingVertices != npolys) { previousRemainingVertices = npolys; remainingIterations = npolys; }
+        else remainingIterations--;
+        ObjIndex ind[3];
+        float vx[3], vy[3];
+        for (size_t k = 0; k < 3; k++) {
+            ind[k] = rem[(guess_vert + k) % npolys];
+            vx[k] = v[(size_t)ind[k].v * 3 + axes[0]];
+            vy[k] = v[(size_t)ind[k].v * 3 + axes[1]];
+        }
+        const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+        const float cross = e0x * e1y - e0y * e1x;
+        const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+        if (cross * area < 0.0f) { guess_vert += 1; continue; }
+        bool overlap = false;
+        for (size_t otherVert = 3; otherVert < npolys; ++otherVert) {
+            const size_t idx = (guess_vert + otherVert) % npolys;
+            const float tx = v[(size_t)rem[idx].v * 3 + axes[0]], ty = v[(size_t)rem[idx].v * 3 + axes[1]];
+            if (pnpoly3(vx, vy, tx, ty)) { overlap = true; break; }
+        }
+        if (overlap) { guess_vert += 1; continue; }
+        push_tri(ind);
+        size_t removed = (guess_vert + 1) % npolys;
+        while (removed + 1 < npolys) { rem[removed] = rem[removed + 1]; removed += 1; }
+        rem.pop_back();
+    }
+    if (rem.size() == 3) push_tri(rem.data());
+}
+
 // Scene::loadObj (src/scene.cpp:38-234): triangles in file order, Vertex{position, texcoord}
 int load_obj(const std::string &base_dir, const std::string &objpath, ptx_scene &sc, ptx_geom &g, std::vector<float> &faces,
              std::vector<uint8_t> tex[4]) {
@@ -230,12 +298,13 @@ int load_obj(const std::string &base_dir, const std::string &objpath, ptx_scene 
         else if (t[0] == "f") {
             int nc = (int)t.size() - 1;
             if (nc < 3) continue;                                   // "Degenerated face", tinyobj skips it
-            if (nc > 4) return fail(PTX_ERR_UNSUPPORTED, "OBJ polygons with more than 4 corners are not supported: " + full);
-            ObjIndex c[4];
+            std::vector<ObjIndex> cv((size_t)nc);
             for (int k = 0; k < nc; k++)
-                if (!parse_face_corner(t[1 + k], (int)v.size() / 3, (int)vt.size() / 2, c[k]))
+                if (!parse_face_corner(t[1 + k], (int)v.size() / 3, (int)vt.size() / 2, cv[k]))
                     return fail(PTX_ERR_INVALID, "bad face record in " + full + ": " + line);
+            const ObjIndex *c = cv.data();
             if (nc == 3) { push_tri(c); }
+            else if (nc > 4) { triangulate_ngon(cv, v, push_tri); }
             else {
                 const float *p0 = &v[c[0].v * 3], *p1 = &v[c[1].v * 3], *p2 = &v[c[2].v * 3], *p3 = &v[c[3].v * 3];
                 float e02[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};

@@ -174,6 +174,26 @@ def jpeg_textures(R):
     print("jpeg_textures.npz:", len(out) // 2, "files (written with PIL %s)" % PIL.__version__)
 
 
+def ngon_faces(R):
+    """tests/ngoncases.py through the reference's loader (tinyobjloader's ear clipping for polygons with > 4 corners)."""
+    import tempfile
+    import ngoncases
+    with tempfile.TemporaryDirectory() as root:
+        for d in ("scenes", "models/materials"):
+            os.makedirs(os.path.join(root, d))
+        text = ngoncases.obj_text()
+        with open(os.path.join(root, "models", "n.obj"), "w") as f:
+            f.write(text)
+        with open(os.path.join(root, "models", "materials", "cube.mtl"), "w") as f:
+            f.write(open(os.path.join(REPO_ROOT, "models", "materials", "cube.mtl")).read())
+        with open(os.path.join(root, "scenes", "s.txt"), "w") as f:
+            f.write(open(os.path.join(REPO_SCENES, "sphere.txt")).read() + "\nOBJECT 1\nobj\n../models/n.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n")
+        R.load(os.path.join(root, "scenes", "s.txt"), cwd=os.path.join(root, "scenes"))
+        faces = np.asarray(R.dump()["faces"][1], np.float32)
+    np.savez_compressed(os.path.join(HERE, "loader_ngons.npz"), faces=faces, obj=np.frombuffer(text.encode(), np.uint8))
+    print("loader_ngons.npz:", len(faces), "triangles")
+
+
 def main():
     so = build_ref()
     if not so:
@@ -327,6 +347,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "fullres_counts.npz"), **full)
     png_textures(R)
     jpeg_textures(R)
+    ngon_faces(R)
     print("golden fixtures written to", HERE)
 
 

@@ -214,3 +214,22 @@ def test_broken_jpeg_is_a_failed_load_not_a_crash(product, tmp_path):
         d = product.Scene(_jpeg_scene(tmp_path, v)).dump()
         t = d["textures"].get((1, 0))
         assert t is None or (t.ndim == 3 and t.shape[2] in (1, 3) and t.size <= 1 << 22)
+
+
+def test_polygons_with_more_than_four_corners(product, tmp_path):
+    """65 pentagons ... dodecagons (convex, concave, star-shaped, non-planar, in all three coordinate planes, with collinear
+    and repeated vertices) come out as the same 332 triangles, in the same order, as from the reference's loader
+    (tinyobjloader's built-in ear clipping; tests/golden/loader_ngons.npz)."""
+    import ngoncases
+    g = golden("loader_ngons.npz")
+    text = ngoncases.obj_text()
+    assert text.encode() == bytes(g["obj"])
+    for d in ("scenes", "models/materials"):
+        os.makedirs(tmp_path / d)
+    (tmp_path / "models" / "n.obj").write_text(text)
+    (tmp_path / "models" / "materials" / "cube.mtl").write_text(open(os.path.join(ROOT, "models", "materials", "cube.mtl")).read())
+    (tmp_path / "scenes" / "s.txt").write_text(open(os.path.join(ROOT, "scenes", "sphere.txt")).read() +
+                                               "\nOBJECT 1\nobj\n../models/n.obj\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 1 1 1\n")
+    d = product.Scene(str(tmp_path / "scenes" / "s.txt")).dump()
+    got = np.asarray(d["faces"][1], np.float32)
+    assert got.shape == g["faces"].shape == (332, 15) and beq(got, g["faces"])
