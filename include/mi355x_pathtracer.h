@@ -201,12 +201,13 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
-/* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
 /* CPU-only (no GPU call): the mesh BVH of csrc/pt_bvh.h against the reference's loop over all faces
    (src/intersections.h:213-233) on `nrays` object-space rays (6 floats: origin, direction).  stats4 = nodes, leaf
-   triangles, nodes visited in total, 0.  */
+   triangles, nodes visited in total, rays on which the front-to-back traversal (the one k_mesh uses) disagrees with
+   the skip-link traversal in face, distance or barycentrics (must be 0).  */
 int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, int nrays, int32_t *face_loop, float *t_loop,
                         int32_t *face_bvh, float *t_bvh, int64_t *stats4);
+/* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
 int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]);
 /* fields14 (optional): 14 rows of min(n, cap) floats: px py pz (= origin + t*direction, the point that will be
  * shaded) dx dy dz cr cg cb nx ny nz u v (u, v only meaningful when the scene has textures) */

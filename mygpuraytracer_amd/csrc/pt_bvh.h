@@ -41,8 +41,9 @@ inline double area(const double lo[3], const double hi[3]) {
     return x * y + y * z + z * x;
 }
 
-inline int buildRec(std::vector<Prim> &pr, std::vector<Node> &out, int a, int b, int depth) {
+inline int buildRec(std::vector<Prim> &pr, std::vector<Node> &out, int a, int b, int depth, int &maxdepth) {
     const int id = (int)out.size();
+    if (depth > maxdepth) maxdepth = depth;
     out.emplace_back();
     {
         Node &nd = out[id];
@@ -103,16 +104,16 @@ inline int buildRec(std::vector<Prim> &pr, std::vector<Node> &out, int a, int b,
         mid = a + n / 2;                  // all centroids coincide: split by position in the list
     }
     if (mid <= a || mid >= b) mid = a + n / 2;
-    const int l = buildRec(pr, out, a, mid, depth + 1);
-    const int r = buildRec(pr, out, mid, b, depth + 1);
+    const int l = buildRec(pr, out, a, mid, depth + 1, maxdepth);
+    const int r = buildRec(pr, out, mid, b, depth + 1, maxdepth);
     out[id].left = l; out[id].right = r; out[id].size = 1 + out[l].size + out[r].size;
     return id;
 }
 }  // namespace bvh_detail
 
 // Appends the tree of faces [faceStart, faceStart + faceCount) (15 floats each: 3 x (pos xyz, uv)) to `out`;
-// tri9 holds v0, e1, e2 per face as uploaded for the plain loop.  Returns the root's node index.
-inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int faceCount, BvhBuild &out) {
+// tri9 holds v0, e1, e2 per face as uploaded for the plain loop.  Returns the root's node index (and the tree's depth).
+inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int faceCount, BvhBuild &out, int *depth_out = nullptr) {
     using namespace bvh_detail;
     std::vector<Prim> pr((size_t)faceCount);
     for (int j = 0; j < faceCount; j++) {
@@ -128,7 +129,9 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
     }
     std::vector<Node> tree;
     tree.reserve((size_t)faceCount * 2);
-    buildRec(pr, tree, 0, faceCount, 0);
+    int maxdepth = 0;
+    buildRec(pr, tree, 0, faceCount, 0, maxdepth);
+    if (depth_out) *depth_out = maxdepth;          // root = depth 0; the ordered traversal needs a stack of depth + 1 entries
     double mdiag = 0.0;
     for (int k = 0; k < 3; k++) mdiag += (tree[0].hi[k] - tree[0].lo[k]) * (tree[0].hi[k] - tree[0].lo[k]);
     mdiag = std::sqrt(mdiag);

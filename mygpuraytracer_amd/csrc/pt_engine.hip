@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p)
         Ray r;
         r.o = V3(st.px()[i], st.py()[i], st.pz()[i]);
         r.d = V3(st.dx()[i], st.dy()[i], st.dz()[i]);
-        const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r);
+        const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r, -1, pt_lds + threadIdx.x, 256);
         if (key != KEY_NONE) atomicMin(&keys[i], key);
     }
 }
@@ -967,7 +967,7 @@ struct ptx_tracer {
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
-    BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr;   // pt_bvh.h (NULL: no mesh has one)
+    BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr, *d_bvh_depth = nullptr;   // pt_bvh.h (NULL: no mesh has one)
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
     int mesh_chunks = 1;                                 // see DScene::mesh_chunks
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
@@ -1007,7 +1007,7 @@ struct ptx_tracer {
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
-        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
+        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
         s.fnorm = d_fnorm; s.cnorm = d_cnorm; s.bump_bits = bump_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
@@ -1070,7 +1070,7 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
@@ -1191,7 +1191,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             mq.sc = t->scene();                                   // tables in global memory
             mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
             mq.seg_stage = bp.seg_stage; mq.seg_keys = bp.seg_keys; mq.seg_items = bp.seg_items;
-            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), 0, stream, mq));
+            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), sizeof(int32_t) * BVH_STACK * 256, stream, mq));
             if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
             else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
         } else {
@@ -1357,10 +1357,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // a BVH for every mesh with enough faces to repay it (pt_bvh.h); its nodes and leaf triangles stay in global memory
     {
         BvhBuild bb;
-        std::vector<int32_t> roots((size_t)std::max(ngeoms, 1), -1);
+        std::vector<int32_t> roots((size_t)std::max(ngeoms, 1), -1), depths((size_t)std::max(ngeoms, 1), 0);
         for (int i = 0; i < ngeoms; i++)
             if (hg[i].type == G_OBJ && hg[i].faceCount >= BVH_MIN_FACES && !opt.no_bvh) {
-                roots[i] = bvhBuild(hfaces.data(), htri9.data(), hg[i].faceStart, hg[i].faceCount, bb);
+                roots[i] = bvhBuild(hfaces.data(), htri9.data(), hg[i].faceStart, hg[i].faceCount, bb, &depths[i]);
                 t->bvh_meshes++;
             }
         t->bvh_nodes = (int)(bb.nodes.size() / 2);
@@ -1374,6 +1374,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             HC(hipMemcpy(t->d_bvh_tris, bb.tris.data(), sizeof(float) * bb.tris.size(), hipMemcpyHostToDevice));
             HC(hipMalloc(&t->d_bvh_root, sizeof(int32_t) * roots.size()));
             HC(hipMemcpy(t->d_bvh_root, roots.data(), sizeof(int32_t) * roots.size(), hipMemcpyHostToDevice));
+            HC(hipMalloc(&t->d_bvh_depth, sizeof(int32_t) * depths.size()));
+            HC(hipMemcpy(t->d_bvh_depth, depths.data(), sizeof(int32_t) * depths.size(), hipMemcpyHostToDevice));
         }
     }
     // materials and geom tables go to LDS; the triangle tables join them when that leaves room for at least 2 workgroups
@@ -1840,8 +1842,9 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
         for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k] - f[k]; o[6 + k] = f[10 + k] - f[k]; }
     }
     BvhBuild bb;
-    const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb);
-    long long visited = 0;
+    int depth = 0;
+    const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb, &depth);
+    long long visited = 0, visited_ordered = 0, mismatches = 0;
     for (int i = 0; i < nrays; i++) {
         const vec3 o = V3(rays6[i * 6 + 0], rays6[i * 6 + 1], rays6[i * 6 + 2]);
         const vec3 d = normalize(V3(rays6[i * 6 + 3], rays6[i * 6 + 4], rays6[i * 6 + 5]));
@@ -1849,10 +1852,19 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
         float b0, b1;
         t_loop[i] = loopNearestHost(faces15, tri9.data(), nfaces, o, d, f0);
         t_bvh[i] = bvhNearest(bb.nodes.data(), bb.tris.data(), root, o, d, f1, b0, b1, &vis);
+        if (depth < BVH_STACK) {                // the front-to-back search must agree with the skip-link one
+            int f2, vis2 = 0;
+            float c0, c1;
+            int32_t stack[BVH_STACK];
+            const float t2 = bvhNearestOrdered(bb.nodes.data(), bb.tris.data(), root, o, d, f2, c0, c1, stack, 1, &vis2);
+            visited_ordered += vis2;
+            if (f2 != f1 || memcmp(&t2, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&c0, &b0, 4) != 0 || memcmp(&c1, &b1, 4) != 0))) mismatches++;
+        }
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;
     }
-    if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / 16); stats4[2] = visited; stats4[3] = 0; }
+    if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / 16); stats4[2] = visited; stats4[3] = mismatches; }
+    (void)visited_ordered;
     return PTX_OK;
 }
 

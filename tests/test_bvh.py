@@ -60,6 +60,7 @@ def assert_same(res):
     fl, tl, fb, tb, st = res
     assert beq(fl, fb), "faces differ at %s" % np.nonzero(fl != fb)[0][:8]
     assert beq(tl, tb)
+    assert st[3] == 0, "front-to-back traversal disagrees with the skip-link traversal on %d rays" % st[3]
     return fl, st
 
 
