@@ -115,13 +115,22 @@ __device__ __forceinline__ PathSoA soa_fresh(PathSoA s) {
 
 struct TileMap {           // which pixels this device owns (row blocks round-robin over tile_world)
     int32_t W, H, tile_rows, tile_rank, tile_world, owned;
+    uint32_t w_mul, w_sh, rows_mul, rows_sh;     // n / W and n / tile_rows as multiply-high + shift (fastdiv), set by the host
 };
 
+// n / d for 0 <= n < 2^31 and a divisor fixed at create: q = (n * mul) >> (32 + sh) with mul = floor(2^(32+sh) / d) + 1,
+// sh = ceil(log2 d) - 1 (exact for that range: the classic invariant-divisor multiply); sh = 255 marks d == 1.
+// Keeps the compiler's generic division -- a dozen instructions and a loop-invariant reciprocal that it spills -- out of
+// the tile loop.
+__device__ __forceinline__ int fastdiv(int n, uint32_t mul, uint32_t sh) {
+    return sh == 255u ? n : (int)(__umulhi((uint32_t)n, mul) >> sh);
+}
+
 __device__ __forceinline__ void owned_pixel(const TileMap &tm, int i, int &x, int &y) {
-    int r = i / tm.W;
+    int r = fastdiv(i, tm.w_mul, tm.w_sh);
     x = i - r * tm.W;
     if (tm.tile_world <= 1) { y = r; return; }
-    int k = r / tm.tile_rows;
+    int k = fastdiv(r, tm.rows_mul, tm.rows_sh);
     y = (k * tm.tile_world + tm.tile_rank) * tm.tile_rows + (r - k * tm.tile_rows);
 }
 
@@ -1027,6 +1036,15 @@ PathSoA soa_shift(PathSoA s, size_t off) {       // host side of soa_offset: the
     return s;
 }
 
+// multiplier and shift of fastdiv (device) for the divisor d >= 1
+void fastdiv_magic(uint32_t d, uint32_t &mul, uint32_t &sh) {
+    if (d <= 1) { mul = 0; sh = 255; return; }
+    int l = 0;
+    while ((1ull << l) < d) l++;
+    sh = (uint32_t)(l - 1);
+    mul = (uint32_t)(((1ull << (31 + l)) / d) + 1);
+}
+
 void camera_to_device(const ptx_camera &c, DCamera &d) {
     d.resx = c.resolution[0]; d.resy = c.resolution[1];
     memcpy(d.position, c.position, 12); memcpy(d.lookAt, c.lookAt, 12); memcpy(d.view, c.view, 12);
@@ -1300,6 +1318,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // tile split: rows owned by this device
     t->tm.W = W; t->tm.H = H; t->tm.tile_world = opt.tile_world; t->tm.tile_rank = opt.tile_rank;
     t->tm.tile_rows = opt.tile_world > 1 ? opt.tile_rows : H;
+    fastdiv_magic((uint32_t)W, t->tm.w_mul, t->tm.w_sh);
+    fastdiv_magic((uint32_t)t->tm.tile_rows, t->tm.rows_mul, t->tm.rows_sh);
     int owned_rows = 0;
     if (opt.tile_world <= 1) owned_rows = H;
     else for (int y = 0; y < H; y++) if ((y / opt.tile_rows) % opt.tile_world == opt.tile_rank) owned_rows++;
