@@ -663,3 +663,18 @@ def test_png_rgba_maps_render_like_the_oracle(gpu_product, O, tmp_path):
     with gpu_product.Tracer(s3) as T:
         T.render(1, 3)
         assert beq(T.read_image(), img)
+
+
+def test_long_run_of_batches_on_two_streams_is_still_sequential(gpu_product):
+    """900 iterations of a small frame: hundreds of batches alternating between the two streams, gathers chained by
+    events.  Any race on the image or on the per-iteration buffers would show as a difference from the same iterations
+    traced one at a time on one stream; three batch sizes and uneven calls to vary the interleaving."""
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt"), res=(80, 56), depth=7)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s, batch=1, lanes=1) as A:
+        A.render(1, 900)
+        want, rays = A.read_image(), A.stats()["rays_total"]
+    for batch in (0, 3, 8):
+        with gpu_product.Tracer(s, batch=batch) as B:
+            B.render(1, 400); B.render(401, 77); B.render(478, 423)
+            assert beq(B.read_image(), want) and B.stats()["rays_total"] == rays, batch
