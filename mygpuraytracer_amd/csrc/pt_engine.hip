@@ -56,6 +56,7 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #ifndef PT_TILE
 #define PT_TILE 256
 #endif
+constexpr int MAX_LANES = 4;     // launch sets in flight at most (ptx_options.lanes)
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
 #endif
@@ -990,8 +991,8 @@ struct ptx_tracer {
     int kmax = 1;                                        // iterations per launch set (segments)
     int lanes = 1;                                       // launch sets in flight at once, each on a stream of its own with its own
                                                          // kmax segments of every per-iteration buffer (lane 0 = `stream`)
-    hipStream_t stream2 = nullptr;                       // lane 1
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chain[2] = {nullptr, nullptr};
+    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] = `stream`, the others are the tracer's own
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_chain[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     int uses_uv = 0;
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
     unsigned long long *d_stamps = nullptr;              // diagnostic build only
@@ -1096,9 +1097,9 @@ int free_tracer(ptx_tracer *t) {
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
-    if (t->stream2) hipStreamDestroy(t->stream2);
+    for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamDestroy(t->lane_stream[l]);
     if (t->ev_fork) hipEventDestroy(t->ev_fork);
-    if (t->ev_join) hipEventDestroy(t->ev_join);
+    for (hipEvent_t e : t->ev_join) if (e) hipEventDestroy(e);
     for (hipEvent_t e : t->ev_chain) if (e) hipEventDestroy(e);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
     delete t;
@@ -1108,11 +1109,11 @@ int free_tracer(ptx_tracer *t) {
 // Enqueues K iterations (iter_first, iter_first + stride, ...) as K segments of every launch: blockIdx.y picks
 // the segment, each segment is an independent stream with its own buffers, so the launches carry K times the work
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
-// Lane `lane` (0 or 1) works on segments lane*kmax .. of every per-iteration buffer and on its own stream; the image is
-// touched only by k_gather, and the gathers of successive batches are chained by events (wait_prev = the other lane's
-// chain event when the previous batch ran there), so the fp32 sums happen in iteration order whatever the overlap.
-int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane = 0, bool wait_prev = false) {
-    hipStream_t stream = lane == 0 ? t->stream : t->stream2;
+// Lane `lane` works on segments lane*kmax .. of every per-iteration buffer and on its own stream; the image is touched
+// only by k_gather, and the gathers of successive batches are chained by events (prev_lane = the lane the previous batch
+// ran on), so the fp32 sums happen in iteration order whatever the overlap.
+int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane = 0, int prev_lane = -1) {
+    hipStream_t stream = lane == 0 ? t->stream : t->lane_stream[lane];
     const size_t seg0 = (size_t)lane * t->kmax;
     const int nb = t->nbins;
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
@@ -1250,7 +1251,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             t->cap_filled = true;
         }
     }
-    if (wait_prev) HIPCHECK(hipStreamWaitEvent(stream, t->ev_chain[lane ^ 1], 0));      // the previous batch's gather + stats
+    if (prev_lane >= 0 && prev_lane != lane) HIPCHECK(hipStreamWaitEvent(stream, t->ev_chain[prev_lane], 0));      // the previous batch's gather + stats
     if (batched)
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
                            3 * (size_t)t->cam.resx * t->cam.resy, t->d_part + seg0 * 3 * (size_t)t->cam.resx * t->cam.resy, t->d_image);
@@ -1498,11 +1499,14 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->kmax = kmax;
     // two launch sets in flight (one per stream) unless switched off: k_move of one overlaps k_bounce of the other and
     // kernel tails are filled (C4: 0.47 -> 0.37 ms per iteration); needs the per-iteration radiance buffers (kmax > 1)
-    t->lanes = (kmax > 1 && opt.lanes != 1) ? 2 : 1;
+    t->lanes = kmax > 1 ? (opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 2) : 1;
     if (t->lanes > 1) {
-        HC(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
-        HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming)); HC(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-        for (hipEvent_t &e : t->ev_chain) HC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+        for (int l = 0; l < t->lanes; l++) {
+            if (l) HC(hipStreamCreateWithFlags(&t->lane_stream[l], hipStreamNonBlocking));
+            HC(hipEventCreateWithFlags(&t->ev_join[l], hipEventDisableTiming));
+            HC(hipEventCreateWithFlags(&t->ev_chain[l], hipEventDisableTiming));
+        }
     }
     const size_t nseg = (size_t)kmax * t->lanes;
     t->field_stride = nseg * t->cap;
@@ -1602,31 +1606,35 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     HIPCHECK(hipEventRecord(t->ev_start, t->stream));
     // per-kernel timing and the debug capture look at one launch set at a time
     const int nl = (t->lanes > 1 && !t->ktiming && t->capture_bounce < 0 && count > t->kmax) ? t->lanes : 1;
-    if (nl > 1) {
+    auto fork = [&]() -> int {                           // the other lanes start after what is on the main stream so far
         HIPCHECK(hipEventRecord(t->ev_fork, t->stream));
-        HIPCHECK(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
-    }
-    int batch = 0;
-    bool used2 = false;
+        for (int l = 1; l < nl; l++) HIPCHECK(hipStreamWaitEvent(t->lane_stream[l], t->ev_fork, 0));
+        return PTX_OK;
+    };
+    if (nl > 1) { int rc = fork(); if (rc != PTX_OK) return rc; }
+    int batch = 0, prev_lane = -1;
+    bool used[MAX_LANES] = {false, false, false, false};
     for (int k = 0; k < count; batch++) {
         int K = std::min(t->kmax, count - k);
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
         if (t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1)) K = 1;
-        const int lane = nl > 1 ? (batch & 1) : 0;
+        const int lane = nl > 1 ? batch % nl : 0;
         const bool fills = t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1);
-        int rc = enqueue_batch(t, iter_first + k * stride, K, stride, lane, nl > 1 && batch > 0);
+        int rc = enqueue_batch(t, iter_first + k * stride, K, stride, lane, nl > 1 ? prev_lane : -1);
         if (rc != PTX_OK) return rc;
-        if (fills && nl > 1 && lane == 0) {              // the other lane must not read the cache before it is written
-            HIPCHECK(hipEventRecord(t->ev_fork, t->stream));
-            HIPCHECK(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+        if (fills && nl > 1 && lane == 0) {              // the other lanes must not read the cache before it is written
+            rc = fork();
+            if (rc != PTX_OK) return rc;
         }
-        used2 |= lane == 1;
+        used[lane] = true;
+        prev_lane = lane;
         k += K;
     }
-    if (used2) {
-        HIPCHECK(hipEventRecord(t->ev_join, t->stream2));
-        HIPCHECK(hipStreamWaitEvent(t->stream, t->ev_join, 0));
-    }
+    for (int l = 1; l < nl; l++)
+        if (used[l]) {
+            HIPCHECK(hipEventRecord(t->ev_join[l], t->lane_stream[l]));
+            HIPCHECK(hipStreamWaitEvent(t->stream, t->ev_join[l], 0));
+        }
     HIPCHECK(hipEventRecord(t->ev_stop, t->stream));
     t->timing_valid = true;
     return PTX_OK;

@@ -674,7 +674,7 @@ def test_long_run_of_batches_on_two_streams_is_still_sequential(gpu_product):
     with gpu_product.Tracer(s, batch=1, lanes=1) as A:
         A.render(1, 900)
         want, rays = A.read_image(), A.stats()["rays_total"]
-    for batch in (0, 3, 8):
-        with gpu_product.Tracer(s, batch=batch) as B:
+    for batch, lanes in ((0, 0), (3, 0), (8, 0), (5, 3), (4, 4)):
+        with gpu_product.Tracer(s, batch=batch, lanes=lanes) as B:
             B.render(1, 400); B.render(401, 77); B.render(478, 423)
-            assert beq(B.read_image(), want) and B.stats()["rays_total"] == rays, batch
+            assert beq(B.read_image(), want) and B.stats()["rays_total"] == rays, (batch, lanes)
