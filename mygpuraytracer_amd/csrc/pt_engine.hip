@@ -734,7 +734,10 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
     __syncthreads();
     // MOVE_U tiles per step: all loads of a step are issued before the first store, which is what hides the HBM
     // latency here (one tile's 15 loads per lane in flight is not enough at 8 waves per SIMD)
-    constexpr int MOVE_U = 4;
+#ifndef PT_MOVE_U
+#define PT_MOVE_U 6
+#endif
+    constexpr int MOVE_U = PT_MOVE_U;
     for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
         const PathSoA stage = soa_fresh(stage_k), out = soa_fresh(out_k);
         size_t i[MOVE_U];

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B timing of prebuilt library variants (.ab/lib*.so) on one GPU box: bash tools/ab_bench.sh A B C ...
-for rep in 1 2; do
+for rep in $(seq 1 ${AB_REPS:-2}); do
 for v in "$@"; do
   cp .ab/lib$v.so mygpuraytracer_amd/libmi355x_pathtracer.so
   python bench.py --no-cpu-baseline > gpurun_out/ab_$v.log 2>&1
