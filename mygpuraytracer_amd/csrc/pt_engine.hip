@@ -1491,18 +1491,19 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // ~16 GB).  With the first-bounce cache the iterations of a batch all start from the one cached bounce-0 stream
     int kmax = opt.batch;
     if (kmax <= 0) {
-        // about 16 M paths per launch set: 8 iterations of a 1080p frame, up to 32 of a small frame or of one rank's tile
+        // about 24 M paths per launch set: 12 iterations of a 1080p frame, up to 32 of a small frame or of one rank's tile
         // (1/8 of 1080p: 0.058 -> 0.048 ms per iteration with 32 instead of 8), fewer when the buffers would not fit ~16 GB
         const long long owned = std::max(t->tm.owned, 1);
-        long long want = ((16LL << 20) + owned / 2) / owned;
+        long long want = ((24LL << 20) + owned / 2) / owned;
         want = std::min<long long>(32, std::max<long long>(8, want));
         kmax = (int)std::min<long long>(want, std::max<long long>(1, (16LL << 30) / (400LL * owned)));
     }
     if (kmax > 64) kmax = 64;
     t->kmax = kmax;
-    // two launch sets in flight (one per stream) unless switched off: k_move of one overlaps k_bounce of the other and
-    // kernel tails are filled (C4: 0.47 -> 0.37 ms per iteration); needs the per-iteration radiance buffers (kmax > 1)
-    t->lanes = kmax > 1 ? (opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 2) : 1;
+    // three launch sets in flight (one per stream) unless told otherwise: k_move of one overlaps k_bounce of another and
+    // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per
+    // iteration); needs the per-iteration radiance buffers (kmax > 1)
+    t->lanes = kmax > 1 ? (opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3) : 1;
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         for (int l = 0; l < t->lanes; l++) {
