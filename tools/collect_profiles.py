@@ -43,7 +43,7 @@ def main(tag, d_stats, d_fetch, d_write):
     res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 8 --warmup 8 "
                    "--no-cpu-baseline; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
                    "FETCH_SIZE correction (checked in round 1 on k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
-                   "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 8 iterations (batch 8).")
+                   "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 12 iterations (the default batch at 1080p).")
     json.dump(res, open(os.path.join(out, "traffic_%s.json" % tag), "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}))
 

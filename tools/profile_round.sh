@@ -13,9 +13,9 @@ echo "stats pass done"
 rm -rf $R/gpurun_out/prof_stats2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats2 -- python3 $R/bench.py > $R/gpurun_out/prof_bench2.json 2> $R/gpurun_out/prof_stats2.err
 echo "stats pass (default command) done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 8 --warmup 8 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_fetch.err
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --lanes 1 --steps 8 --warmup 8 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_write.err
 echo "write pass done"
 cd $R && python3 bench.py > gpurun_out/bench_plain.json 2> gpurun_out/bench_plain.err
 tail -1 gpurun_out/bench_plain.json | cut -c1-300
