@@ -3,7 +3,7 @@
 // state.iterations iterations of pathtrace, print "time: <ms>" (sum of the bounce-loop timer, main.cpp:141-146) and
 // save <FILE>.<utc>.<n>samp.png with saveImage's mirroring (main.cpp:81-102).
 //
-//   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm]
+//   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr]
 //                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
 //                                  [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]
 //                                  [--orbit "left:DX,DY;right:DY;middle:DX,DY;space"]   (the mouse of main.cpp:166-212, scripted)
@@ -33,11 +33,11 @@ static std::string currentTimeString() {          // src/preview.cpp:13-19
 int main(int argc, char **argv) {
     const std::string startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT]\n", argv[0]);
         return 1;
     }
     int resw = 0, resh = 0, depth = 0, iterations = 0;
-    bool pfm = false;
+    bool pfm = false, hdr = false;
     std::string out_prefix, ckpt_path, resume_path, orbit_script;
     int ckpt_every = 0;
     ptx_options &opt = pathtraceOptions();
@@ -50,6 +50,7 @@ int main(int argc, char **argv) {
         else if (a == "--out") { need(1); out_prefix = argv[++i]; }
         else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
         else if (a == "--pfm") pfm = true;
+        else if (a == "--hdr") hdr = true;
         else if (a == "--checkpoint") { need(1); ckpt_path = argv[++i]; }
         else if (a == "--checkpoint-every") { need(1); ckpt_every = atoi(argv[++i]); }
         else if (a == "--resume") { need(1); resume_path = argv[++i]; }
@@ -114,6 +115,12 @@ int main(int argc, char **argv) {
     if (!ptimg::write_png_rgb8(ss.str() + ".png", width, height, rgb8.data())) { fprintf(stderr, "cannot write %s.png\n", ss.str().c_str()); return 1; }
     printf("Saved %s.png.\n", ss.str().c_str());
     if (pfm) { ptimg::write_pfm(ss.str() + ".pfm", width, height, &scene->state.image[0].x, (float)n); printf("Saved %s.pfm.\n", ss.str().c_str()); }
+    if (hdr) {                                                                          // img.saveHDR, main.cpp:101
+        std::vector<float> mean;
+        ptimg::to_mean_mirrored(width, height, &scene->state.image[0].x, (float)n, mean);
+        if (!ptimg::write_hdr(ss.str() + ".hdr", width, height, mean.data())) { fprintf(stderr, "cannot write %s.hdr\n", ss.str().c_str()); return 1; }
+        printf("Saved %s.hdr.\n", ss.str().c_str());
+    }
     pathtraceFree();
     delete scene;
     return 0;

@@ -2,6 +2,7 @@
 // (src/main.cpp:81-102, src/image.cpp:22-39), without stb_image_write: a self-contained PNG encoder (zlib stream
 // of stored blocks -- valid PNG, no compression) and a PFM writer for the raw fp32 frame.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -90,6 +91,82 @@ inline bool write_pfm(const std::string &path, int w, int h, const float *sum_rg
     }
     fclose(f);
     return true;
+}
+
+// image::saveHDR (src/image.cpp:41-45; the call at src/main.cpp:101 is commented out there, --hdr enables it here):
+// Radiance RGBE file of the same float pixels savePNG gets, i.e. mean radiance, x-mirrored by saveImage.  The bytes are
+// those of the stb_image_write the reference vendors (external/include/stb_image_write.h:250-390): shared exponent of
+// the largest channel via frexp, mantissas truncated; scanlines of width 8..32767 are stored channel-planar with the
+// "2 2 hi lo" marker and per-channel RLE where a run is >= 3 equal bytes (<= 127 per packet) and literals go out in
+// packets of <= 128; other widths are flat RGBE.
+inline void rgbe_of(const float rgb[3], uint8_t out[4]) {
+    float m = rgb[1] > rgb[2] ? rgb[1] : rgb[2];
+    m = rgb[0] > m ? rgb[0] : m;
+    if (m < 1e-32) { out[0] = out[1] = out[2] = out[3] = 0; return; }      // compared in double, as the vendored code does
+    int e;
+    const float scale = (float)frexp(m, &e) * 256.0f / m;
+    for (int k = 0; k < 3; k++) out[k] = (uint8_t)(rgb[k] * scale);
+    out[3] = (uint8_t)(e + 128);
+}
+
+inline void hdr_scanline(std::vector<uint8_t> &o, int w, const float *rgb) {
+    uint8_t q[4];
+    if (w < 8 || w >= 32768) {
+        for (int x = 0; x < w; x++) { rgbe_of(rgb + 3 * x, q); o.insert(o.end(), q, q + 4); }
+        return;
+    }
+    std::vector<uint8_t> plane((size_t)w * 4);
+    for (int x = 0; x < w; x++) { rgbe_of(rgb + 3 * x, q); for (int c = 0; c < 4; c++) plane[(size_t)c * w + x] = q[c]; }
+    o.push_back(2); o.push_back(2); o.push_back((uint8_t)((w >> 8) & 0xff)); o.push_back((uint8_t)(w & 0xff));
+    for (int c = 0; c < 4; c++) {
+        const uint8_t *p = &plane[(size_t)c * w];
+        int x = 0;
+        while (x < w) {
+            int r = x;                                   // first position where three equal bytes start, else the end
+            while (r + 2 < w && !(p[r] == p[r + 1] && p[r] == p[r + 2])) r++;
+            const bool run = r + 2 < w;
+            if (!run) r = w;
+            while (x < r) {                              // literals
+                const int len = r - x > 128 ? 128 : r - x;
+                o.push_back((uint8_t)len); o.insert(o.end(), p + x, p + x + len);
+                x += len;
+            }
+            if (run) {
+                while (r < w && p[r] == p[x]) r++;
+                while (x < r) {
+                    const int len = r - x > 127 ? 127 : r - x;
+                    o.push_back((uint8_t)(len + 128)); o.push_back(p[x]);
+                    x += len;
+                }
+            }
+        }
+    }
+}
+
+// pixels: W*H*3 floats, row-major, top row first, exactly what is to be stored (no division, no mirroring here)
+inline bool write_hdr(const std::string &path, int w, int h, const float *pixels) {
+    if (w <= 0 || h <= 0 || !pixels) return false;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\n");
+    fprintf(f, "EXPOSURE=          1.0000000000000\n\n-Y %d +X %d\n", h, w);
+    std::vector<uint8_t> o;
+    bool ok = true;
+    for (int y = 0; y < h && ok; y++) {
+        o.clear();
+        hdr_scanline(o, w, pixels + (size_t)y * w * 3);
+        ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+    }
+    return fclose(f) == 0 && ok;
+}
+
+// mean radiance, x-mirrored: the float image saveImage hands to savePNG / saveHDR (src/main.cpp:86-92)
+inline void to_mean_mirrored(int w, int h, const float *sum_rgb, float samples, std::vector<float> &out) {
+    out.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int k = 0; k < 3; k++)
+                out[((size_t)(w - 1 - x) + (size_t)y * w) * 3 + k] = sum_rgb[((size_t)x + (size_t)y * w) * 3 + k] / samples;
 }
 
 // Checkpoint of a render in progress: the accumulation buffer (sum over iterations, as ptx_read_image returns it) and

@@ -194,10 +194,31 @@ def ngon_faces(R):
     print("loader_ngons.npz:", len(faces), "triangles")
 
 
+def hdr_files(so):
+    """tests/hdrcases.py through the stbi_write_hdr the reference vendors (what image::saveHDR calls, src/image.cpp:41-45)."""
+    import ctypes
+    import tempfile
+    import hdrcases
+    lib = ctypes.CDLL(so)
+    lib.stbi_write_hdr.restype = ctypes.c_int
+    lib.stbi_write_hdr.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        for name, img in hdrcases.cases().items():
+            path = os.path.join(root, name + ".hdr")
+            assert lib.stbi_write_hdr(path.encode(), img.shape[1], img.shape[0], 3, img.ctypes.data) == 1
+            out[name] = np.frombuffer(open(path, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "hdr_files.npz"), **out)
+    print("hdr_files.npz:", len(out), "files")
+
+
 def main():
     so = build_ref()
     if not so:
         sys.exit("oracle/_ref/libptref.so cannot be built here (no /root/reference)")
+    if sys.argv[1:] == ["hdr"]:                      # only this fixture (the others are unchanged by it)
+        hdr_files(so)
+        return
     R = RefLib(so)
     rng = np.random.default_rng(20261004)
 
@@ -348,6 +369,7 @@ def main():
     png_textures(R)
     jpeg_textures(R)
     ngon_faces(R)
+    hdr_files(so)
     print("golden fixtures written to", HERE)
 
 

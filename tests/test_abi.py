@@ -95,6 +95,38 @@ def test_png_writer_matches_saveimage_semantics(tmp_path):
     assert list(rows[1]) == [127, 63, 12, 255, 255, 255]
 
 
+def test_hdr_writer_matches_savehdr_bytes(tmp_path):
+    """pt_image.h write_hdr: byte-identical files to image::saveHDR (src/image.cpp:41-45), i.e. to the stb_image_write the
+    reference vendors -- tests/golden/hdr_files.npz was written by that code (make_golden.py hdr_files).  Also the live
+    library when oracle/_ref is present."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import hdrcases
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "%s/mygpuraytracer_amd/csrc/pt_image.h"\n'
+                   'int main(int argc, char **argv){ int w = atoi(argv[1]), h = atoi(argv[2]); std::vector<float> px((size_t)w*h*3);\n'
+                   ' FILE *f = fopen(argv[3], "rb"); if (!f || fread(px.data(), 4, px.size(), f) != px.size()) return 2; fclose(f);\n'
+                   ' return ptimg::write_hdr(argv[4], w, h, px.data()) ? 0 : 1; }\n' % ROOT)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(tmp_path / "t"), str(src)])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "hdr_files.npz"))
+    cases = hdrcases.cases()
+    assert sorted(cases) == sorted(gold.files)
+    ref = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
+    live = ctypes.CDLL(ref) if os.path.exists(ref) else None
+    for name, img in cases.items():
+        raw, out = tmp_path / "in.raw", tmp_path / "out.hdr"
+        raw.write_bytes(img.tobytes())
+        subprocess.check_call([str(tmp_path / "t"), str(img.shape[1]), str(img.shape[0]), str(raw), str(out)])
+        got = out.read_bytes()
+        assert got == gold[name].tobytes(), name
+        if live is not None:
+            lp = tmp_path / "live.hdr"
+            live.stbi_write_hdr.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            assert live.stbi_write_hdr(str(lp).encode(), img.shape[1], img.shape[0], 3, img.ctypes.data) == 1
+            assert got == lp.read_bytes(), name
+
+
 def test_headers_are_plain_c_and_link(product, tmp_path):
     """The boundary is a C ABI: both headers compile as C99 (-pedantic) and a C program links against the library and
     calls entry points that need no GPU (what a cgo / JNI / ctypes binding would do)."""

@@ -479,7 +479,7 @@ def test_headless_driver(gpu_product, tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"), "headless"])
     out = subprocess.check_output([exe, os.path.join(ROOT, "scenes", "cornellObj.txt"), "--res", "64", "48", "--depth", "5",
-                                   "--iterations", "3", "--out", str(tmp_path / "img"), "--pfm"], text=True)
+                                   "--iterations", "3", "--out", str(tmp_path / "img"), "--pfm", "--hdr"], text=True)
     assert "time: " in out and "Saved" in out
     pfm = glob.glob(str(tmp_path / "img.*.3samp.pfm"))
     png = glob.glob(str(tmp_path / "img.*.3samp.png"))
@@ -493,6 +493,31 @@ def test_headless_driver(gpu_product, tmp_path):
         T.render(1, 3)
         want = T.read_image().reshape(48, 64, 3) / np.float32(3)
     assert np.array_equal(frame, want)
+    # --hdr = saveHDR: the mirrored mean frame as RGBE (byte parity of the encoder itself: test_abi.py, CPU)
+    hdr = open(glob.glob(str(tmp_path / "img.*.3samp.hdr"))[0], "rb").read()
+    head = b"#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y 48 +X 64\n"
+    assert hdr.startswith(head)
+    pos, rows = len(head), []
+    for _ in range(48):
+        assert hdr[pos:pos + 4] == bytes([2, 2, 0, 64])
+        pos += 4
+        planes = []
+        for _c in range(4):
+            line = b""
+            while len(line) < 64:
+                n = hdr[pos]
+                if n > 128:
+                    line += bytes([hdr[pos + 1]]) * (n - 128); pos += 2
+                else:
+                    line += hdr[pos + 1:pos + 1 + n]; pos += 1 + n
+            assert len(line) == 64
+            planes.append(np.frombuffer(line, np.uint8))
+        rows.append(np.stack(planes, 1))
+    assert pos == len(hdr)
+    rgbe = np.stack(rows).astype(np.float64)
+    dec = rgbe[..., :3] * np.exp2(rgbe[..., 3:] - 136.0)
+    mirrored = want[:, ::-1].astype(np.float64)
+    assert np.all(np.abs(dec - mirrored) <= mirrored.max(axis=2, keepdims=True) / 128 + 1e-30)
     # the same with main.cpp's mouse scripted (--orbit): equals the Python host side driving the same events
     subprocess.check_call([exe, os.path.join(ROOT, "scenes", "cornellObj.txt"), "--res", "64", "48", "--depth", "5", "--iterations", "2",
                            "--out", str(tmp_path / "orb"), "--pfm", "--orbit", "left:11,-4; right:20;middle:30,10"])
