@@ -104,7 +104,7 @@ def main():
                     help="N > 1: 'tiles' = interleaved pixel-row blocks per rank (what north_star prescribes, the default); "
                     "'iterations' = every rank traces the full frame for every N-th iteration (sums to the single-GPU frame)")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="launch sets in flight (ptx_options.lanes): 0 = library default (2: k_move of one batch of 8 iterations "
+                    help="launch sets in flight (ptx_options.lanes): 0 = library default (3: k_move of one batch of iterations "
                     "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
                     "because a kernel's duration is only meaningful when it has the GPU to itself)")
     args = ap.parse_args()

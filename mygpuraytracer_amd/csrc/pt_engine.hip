@@ -992,6 +992,7 @@ struct ptx_tracer {
     int nsuper = 1, ntri = 0, tri_lds = 0;
     size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
     int kmax = 1;                                        // iterations per launch set (segments)
+    long long split_min_paths = 1LL << 20;               // ptx_render_strided: smallest launch set a short run is cut into
     int lanes = 1;                                       // launch sets in flight at once, each on a stream of its own with its own
                                                          // kmax segments of every per-iteration buffer (lane 0 = `stream`)
     hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] = `stream`, the others are the tracer's own
@@ -1504,6 +1505,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per
     // iteration); needs the per-iteration radiance buffers (kmax > 1)
     t->lanes = kmax > 1 ? (opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3) : 1;
+    if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
         for (int l = 0; l < t->lanes; l++) {
@@ -1609,7 +1611,15 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     }
     HIPCHECK(hipEventRecord(t->ev_start, t->stream));
     // per-kernel timing and the debug capture look at one launch set at a time
-    const int nl = (t->lanes > 1 && !t->ktiming && t->capture_bounce < 0 && count > t->kmax) ? t->lanes : 1;
+    // A run shorter than lanes x kmax iterations is cut into equal launch sets, one per lane, as long as each keeps at
+    // least split_min_paths primary rays (below that the launches no longer fill the chip and overlap buys nothing).
+    int kb = t->kmax;
+    if (t->lanes > 1 && count < t->lanes * t->kmax) {
+        const long long owned = std::max(t->tm.owned, 1);
+        const int kmin = (int)std::min<long long>(t->kmax, (t->split_min_paths + owned - 1) / owned);
+        kb = std::min(t->kmax, std::max(kmin, (count + t->lanes - 1) / t->lanes));
+    }
+    const int nl = (t->lanes > 1 && !t->ktiming && t->capture_bounce < 0 && count > kb) ? t->lanes : 1;
     auto fork = [&]() -> int {                           // the other lanes start after what is on the main stream so far
         HIPCHECK(hipEventRecord(t->ev_fork, t->stream));
         for (int l = 1; l < nl; l++) HIPCHECK(hipStreamWaitEvent(t->lane_stream[l], t->ev_fork, 0));
@@ -1619,7 +1629,7 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     int batch = 0, prev_lane = -1;
     bool used[MAX_LANES] = {false, false, false, false};
     for (int k = 0; k < count; batch++) {
-        int K = std::min(t->kmax, count - k);
+        int K = std::min(nl > 1 ? kb : t->kmax, count - k);
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
         if (t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1)) K = 1;
         const int lane = nl > 1 ? batch % nl : 0;

@@ -415,18 +415,23 @@ def test_batched_iterations_identical(gpu_product, batch, tile):
 
 @pytest.mark.parametrize("scene,opt", [("cornell.txt", dict(antialiasing=0)), ("cornellObj.txt", {}), ("cornellObj.txt", dict(antialiasing=0, apps_variant=1))])
 def test_two_launch_sets_in_flight_identical(gpu_product, scene, opt):
-    """Default tracer (batches of 8 iterations alternating between two streams, gathers chained in iteration order;
+    """Default tracer (batches of iterations taking turns over three streams, gathers chained in iteration order;
     with AA off also the batched first-bounce cache: every iteration of a batch starts from the one cached bounce-0
     stream) against one iteration at a time on one stream: same image bits, same ray totals, over several calls."""
     pt = gpu_product
     s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(200, 120), depth=7)
     s.apply_runcuda_camera()
-    with pt.Tracer(s, batch=1, lanes=1, **opt) as A, pt.Tracer(s, **opt) as B, pt.Tracer(s, lanes=1, **opt) as C:
+    os.environ["PTX_DEBUG_SPLIT_MIN"] = "1"       # D: runs shorter than lanes x batch are cut into one launch set per lane
+    try:
+        D = pt.Tracer(s, **opt)
+    finally:
+        del os.environ["PTX_DEBUG_SPLIT_MIN"]
+    with pt.Tracer(s, batch=1, lanes=1, **opt) as A, pt.Tracer(s, **opt) as B, pt.Tracer(s, lanes=1, **opt) as C, D:
         for first, count in ((1, 37), (38, 5), (43, 20)):
-            A.render(first, count); B.render(first, count); C.render(first, count)
+            A.render(first, count); B.render(first, count); C.render(first, count); D.render(first, count)
             a = A.read_image()
-            assert beq(a, B.read_image()) and beq(a, C.read_image())
-            assert A.stats()["rays_total"] == B.stats()["rays_total"] == C.stats()["rays_total"]
+            assert beq(a, B.read_image()) and beq(a, C.read_image()) and beq(a, D.read_image())
+            assert A.stats()["rays_total"] == B.stats()["rays_total"] == C.stats()["rays_total"] == D.stats()["rays_total"]
         B.reset_image(); A.reset_image()
         A.render(5, 19); B.render(5, 19)                               # cache refilled by an iteration other than 1
         assert beq(A.read_image(), B.read_image())
