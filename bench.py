@@ -119,7 +119,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
-    if world > 1:
+    # collectives also with one rank when launched under torch.distributed.run with PTX_BENCH_DIST=1: a rehearsal of the
+    # RCCL calls (init, reduce, barrier, all_reduce) on a one-GPU box
+    dist_on = world > 1 or (os.environ.get("PTX_BENCH_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -165,27 +168,27 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     T.render(1, args.warmup)
     T.synchronize()
-    if world > 1:                                   # warm the collective too
+    if dist_on:                                     # warm the collective too
         reduce_frame(image.clone())
     rays0 = T.stats()["rays_total"]
     barrier()
     t0 = time.perf_counter()
     render_steps(args.warmup + 1, args.steps)       # EXACTLY K steps, enqueued back to back on the tracer's stream
     T.synchronize()
-    if world > 1:                                   # one RCCL reduce of the accumulation buffer per run
+    if dist_on:                                     # one RCCL reduce of the accumulation buffer per run
         reduce_frame(image)
     barrier()
     dt = time.perf_counter() - t0
     st = T.stats()
     rays = st["rays_total"] - rays0
     loop_ms = T.last_loop_ms()
-    if world > 1:
+    if dist_on:
         dt = float(all_reduce_scalar(dt, torch.float64, dist.ReduceOp.MAX))
         rays = int(all_reduce_scalar(rays, torch.int64, dist.ReduceOp.SUM))
 
@@ -222,7 +225,7 @@ def main():
                               loop_ms_per_step=loop_ms / args.steps),
                     kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()},
                     timing="kernel durations: hipEvents around every launch, one launch set at a time (lanes 1); value, ms_per_step "
-                           "and loop: wall time with %d launch set(s) in flight" % (1 if args.lanes == 1 else 2))
+                           "and loop: wall time with %d launch set(s) in flight" % (args.lanes if args.lanes >= 1 else 3))
 
     out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
@@ -237,7 +240,7 @@ def main():
     T.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
