@@ -54,15 +54,33 @@ def cpu_baseline(scene, iters):
     counts = [int(c) for c in O.live_counts()]
     SC = pt.StreamCompaction()
     rng = np.random.default_rng(1)
-    ms = dict(cpu_without_scan=0.0, cpu_with_scan=0.0, gpu_efficient_compact=0.0)
+    import torch
+    ms = dict(cpu_without_scan=0.0, cpu_with_scan=0.0, gpu_efficient_compact=0.0, gpu_compact_device=0.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
     for b, n in enumerate(counts):
         alive = counts[b + 1] if b + 1 < len(counts) else 0
         flags = np.zeros(n, np.int32)
         flags[rng.permutation(n)[:alive]] = 1
         a = SC.cpu_compact_without_scan(flags); ms["cpu_without_scan"] += SC.last_cpu_ms()
         c = SC.cpu_compact_with_scan(flags); ms["cpu_with_scan"] += SC.last_cpu_ms()
+        # the reference-shaped entry point: host pointers, allocates and copies inside (efficient.cu:79-136)
         g = SC.efficient_compact(flags); ms["gpu_efficient_compact"] += SC.last_gpu_ms()
         assert len(a) == len(c) == len(g) == alive
+        # the same array already in HBM, buffers reused (sc_compact_device), mean of 20 calls
+        d_in, d_out = torch.from_numpy(flags).to(dev), torch.empty(n, dtype=torch.int32, device=dev)
+        ws = torch.zeros((SC.workspace_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        SC.compact_device(n, d_out.data_ptr(), d_in.data_ptr(), cnt.data_ptr(), ws.data_ptr(), stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            SC.compact_device(n, d_out.data_ptr(), d_in.data_ptr(), cnt.data_ptr(), ws.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms["gpu_compact_device"] += e0.elapsed_time(e1) / 20
+        assert int(cnt.item()) == alive
     # the reference's own code (oracle/_ref: its headers and loader compiled for the host, where it has been built) on
     # three iterations of the same frame, next to the port
     reference = None
@@ -89,6 +107,43 @@ def cpu_baseline(scene, iters):
                 stream_compaction_ms_per_iteration=dict(elements=sum(counts), **ms),
                 sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
+
+
+def stream_compaction_device(torch, pt, device):
+    """the scan / compaction library on arrays already in HBM (sc_scan_device, sc_compact_device): achieved
+    rate on algorithmic bytes (scan 4 B read + 4 B written per element; compaction 4 B read + 4 B per survivor) next to a
+    device-to-device copy of the same array.  n = 2^28 ints (1 GiB, past the 256 MB Infinity Cache) and the C4 frame."""
+    sc = pt.StreamCompaction()
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = []
+    for n in (1 << 28, RES[0] * RES[1]):
+        g = torch.Generator(device=device)
+        g.manual_seed(n)
+        a = (torch.rand(n, device=device, generator=g) < 0.46).to(torch.int32) * 3     # 46 % survive, as in C4's first bounce
+        o = torch.empty_like(a)
+        ws = torch.zeros((sc.workspace_bytes(n) + 7) // 8, dtype=torch.int64, device=device)
+        count = torch.zeros(1, dtype=torch.int32, device=device)
+        reps = 5 if n > (1 << 24) else 50
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+        t_scan = timed(lambda: sc.scan_device(n, o.data_ptr(), a.data_ptr(), ws.data_ptr(), stream))
+        t_comp = timed(lambda: sc.compact_device(n, o.data_ptr(), a.data_ptr(), count.data_ptr(), ws.data_ptr(), stream))
+        kept = int(count.item())
+        t_copy = timed(lambda: o.copy_(a))
+        rows.append(dict(n=n, scan_GBps=8 * n / t_scan / 1e9, scan_frac_of_hbm_peak=8 * n / t_scan / HBM_PEAK,
+                         compact_GBps=(4 * n + 4 * kept) / t_comp / 1e9, survivors=kept, copy_GBps=8 * n / t_copy / 1e9,
+                         scan_us=t_scan * 1e6, compact_us=t_comp * 1e6, copy_us=t_copy * 1e6))
+        del a, o, ws
+    return rows
 
 
 def main():
@@ -238,6 +293,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)
     T.close()
+    if rank == 0 and world == 1:
+        out["stream_compaction"] = stream_compaction_device(torch, pt, device)
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

@@ -13,8 +13,8 @@
  *
  * Same argument meaning as the reference: n elements, host pointers in and out (the GPU variants allocate and
  * copy internally, exactly like the reference's), exclusive prefix sum, compaction keeps non-zero elements in
- * order and returns their count.  The three GPU scan entry points are one implementation here (a work-efficient
- * block scan + block-sum scan written for wave64; the reference's O(log n)-launch Naive and Blelloch variants are
+ * order and returns their count.  The three GPU scan entry points are one implementation here (a single-pass chained
+ * scan with decoupled look-back written for wave64; the reference's O(log n)-launch Naive and Blelloch variants are
  * teaching steps, not something to preserve) and give identical results.  The *_device forms take device
  * pointers and a hipStream_t and do no allocation or copy: that is what a production caller wants.
  * GPU entry points return 0 on success, non-zero (PTX_ERR_*) on failure with the message in ptx_last_error().
@@ -36,7 +36,8 @@ int sc_thrust_scan(int n, int *odata, const int *idata);
 /* returns the number of elements kept, or -1 on failure */
 int sc_efficient_compact(int n, int *odata, const int *idata);
 
-/* device-pointer forms; workspace: sc_scan_workspace_bytes(n) bytes of device memory */
+/* device-pointer forms; workspace: sc_scan_workspace_bytes(n) bytes of device memory, 8-byte aligned, contents arbitrary;
+ * the scan may run in place (d_odata == d_idata), the compaction may not */
 unsigned long long sc_scan_workspace_bytes(int n);
 int sc_scan_device(int n, int *d_odata, const int *d_idata, void *d_workspace, void *stream);
 int sc_compact_device(int n, int *d_odata, const int *d_idata, int *d_count, void *d_workspace, void *stream);

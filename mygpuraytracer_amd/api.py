@@ -574,6 +574,16 @@ class StreamCompaction:
             raise PathTracerError("sc_efficient_compact failed: %s" % self.lib.ptx_last_error().decode())
         return out[:n].copy()
 
+    # device-pointer forms (addresses as ints, e.g. torch tensor.data_ptr(); stream = a hipStream_t handle or 0)
+    def workspace_bytes(self, n):
+        return int(self.lib.sc_scan_workspace_bytes(int(n)))
+
+    def scan_device(self, n, d_out, d_in, d_workspace, stream=0):
+        _check(self.lib.sc_scan_device(int(n), d_out, d_in, d_workspace, stream), "sc_scan_device")
+
+    def compact_device(self, n, d_out, d_in, d_count, d_workspace, stream=0):
+        _check(self.lib.sc_compact_device(int(n), d_out, d_in, d_count, d_workspace, stream), "sc_compact_device")
+
     def last_gpu_ms(self):
         return float(self.lib.sc_last_gpu_ms())
 

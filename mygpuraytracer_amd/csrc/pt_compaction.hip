@@ -1,16 +1,25 @@
 // pt_compaction.hip -- scan / stream compaction on int arrays behind include/mi355x_stream_compaction.h.
 //
 // Replaces the reference's stream_compaction/{cpu,naive,efficient,thrust,common}.cu.  The reference's GPU scans
-// issue one launch per tree level (2*log2(n)+1 launches for the Blelloch version, efficient.cu:46-61); here a
-// scan is three launches regardless of n, written for 64-wide wavefronts:
-//   k_block_scan : each 256-thread workgroup scans 2048 elements (8 per lane as two 16-byte loads, wave scan by
-//                  __shfl_up, 4 wave totals through LDS) and emits its total;
-//   k_sums_scan  : one workgroup scans the block totals (running carry, any count);
-//   k_add_offsets: adds each block's offset.
-// Compaction fuses kernMapToBoolean (common.cu:25-34) into the first pass and ends with kernScatter (:40-49).
-// HBM traffic: scan reads n and writes n ints twice (8+8 B/elem); compaction adds one read and <= one write.
+// issue one launch per tree level (2*log2(n)+1 launches for the Blelloch version, efficient.cu:46-61) and its
+// compaction is map + scan + scatter over three int arrays (efficient.cu:79-136).  Here either is ONE pass over the
+// data -- a chained scan with decoupled look-back, written for 64-wide wavefronts:
+//   * a workgroup (512 threads for the scan, 1024 for compaction) takes the next 16384-element tile (ticket from an
+//     atomic counter, so a tile's predecessors are always resident or done), loaded as coalesced non-temporal
+//     16-byte loads, 8 or 4 per lane;
+//   * scan inside the tile: 4 per lane per load in registers, wave scan by __shfl_up, the 64 (load, wave) totals
+//     scanned by wave 0 through LDS;
+//   * the tile publishes {flag, total} as one 8-byte word (relaxed agent-scope store: one granule, no fence needed,
+//     visible across the XCDs' L2s) and its wave 0 looks back over its predecessors' words, 64 per step, adding
+//     tile totals until it meets one that already knows its inclusive prefix, then publishes its own;
+//   * scan: the prefixes are stored; compaction (kernMapToBoolean fused, common.cu:25-34): the survivors of the
+//     tile are packed in LDS and stored as one contiguous run (kernScatter, common.cu:40-49, without the index array).
+// HBM traffic is the algorithmic minimum: scan 4 B read + 4 B written per element, compaction 4 B read + 4 B per
+// survivor, plus 8 B per tile of status words (zeroed by a memset node in front of the kernel).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <string>
 #include <string.h>
 
@@ -21,9 +30,18 @@ extern "C" void ptx_internal_set_error(const char *msg);
 
 namespace {
 
-constexpr int SC_THREADS = 256;
-constexpr int SC_ITEMS = 8;
-constexpr int SC_BLOCK = SC_THREADS * SC_ITEMS;     // 2048 elements per workgroup
+constexpr int SC_TILE = 16384;                                 // elements (64 KB) per workgroup: one ticket each, and one
+                                                               // address takes only ~80 M atomics/s across the XCDs
+// 64 (round, wave) totals per tile either way (one lane each in the second-level scan); measured on 2^28 ints:
+// scan 1024 x 4: 4.39 TB/s, 512 x 8: 4.57 TB/s; compaction 1024 x 4: 3.75 TB/s, 512 x 8: 3.60 TB/s (copy: 4.9-5.0);
+// at least 4 waves per SIMD (<= 128 registers): asking for 8 spills and is 5 % slower
+constexpr int SC_SCAN_THREADS = 512, SC_COMPACT_THREADS = 1024;
+constexpr int SC_HEAD = 64;                                    // workspace: [ticket, padding to 64 B][status word per tile]
+
+typedef unsigned long long u64;
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr u64 ST_AGGREGATE = 1ull << 32;                       // low word = this tile's total
+constexpr u64 ST_INCLUSIVE = 2ull << 32;                       // low word = total of this tile and everything before it
 
 thread_local float g_gpu_ms = 0.f, g_cpu_ms = 0.f;
 
@@ -39,97 +57,140 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
     return v;
 }
 
-// exclusive scan inside each 2048-element block; MAP: scan (x != 0) instead of x
-template <bool MAP>
-__global__ __launch_bounds__(SC_THREADS) void k_block_scan(int n, const int *__restrict__ in, int *__restrict__ out,
-                                                            int *__restrict__ block_sums) {
-    __shared__ int wave_tot[SC_THREADS / 64];
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// COMPACT = false: out[i] = in[0] + .. + in[i-1].  COMPACT = true: out = the non-zero elements of in, in order;
+// *count = how many.  A tile waits only for tiles with lower tickets, which are resident or done and post their totals
+// before they wait for anything themselves: every wait ends.
+template <bool COMPACT, int SC_THREADS>
+__global__ __launch_bounds__(SC_THREADS, 4) void k_onepass(int n, const int *__restrict__ in, int *__restrict__ out,
+                                                            unsigned *__restrict__ ticket, u64 *__restrict__ status,
+                                                            int *__restrict__ count) {
+    constexpr int SC_WAVES = SC_THREADS / 64, SC_ROUNDS = SC_TILE / (SC_THREADS * 4);       // 16-byte loads per lane
+    __shared__ int s_tile, s_excl, s_total;
+    __shared__ int s_wtot[SC_ROUNDS * SC_WAVES];              // (round, wave) totals, then their exclusive prefixes
+    __shared__ int s_stage[COMPACT ? SC_TILE : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long base = (long long)blockIdx.x * SC_BLOCK + (long long)tid * SC_ITEMS;
-    int v[SC_ITEMS];
-    if (base + SC_ITEMS <= n && ((((uintptr_t)(in + base)) & 15) == 0)) {
-        const int4 a = *reinterpret_cast<const int4 *>(in + base);
-        const int4 b = *reinterpret_cast<const int4 *>(in + base + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const long long tbase = (long long)tile * SC_TILE;
+    const bool whole = tbase + SC_TILE <= n;
+
+    int x[SC_ROUNDS][4];
+    if (whole && (((uintptr_t)in) & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < SC_ROUNDS; r++) {
+            // streamed once: non-temporal loads and stores (+5 % on 1 GiB)
+            const v4i a = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(in + tbase + (r * SC_THREADS + tid) * 4));
+            x[r][0] = a.x; x[r][1] = a.y; x[r][2] = a.z; x[r][3] = a.w;
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < SC_ITEMS; k++) v[k] = (base + k < n) ? in[base + k] : 0;
-    }
-    if (MAP) {
+        for (int r = 0; r < SC_ROUNDS; r++)
 #pragma unroll
-        for (int k = 0; k < SC_ITEMS; k++) v[k] = v[k] != 0 ? 1 : 0;
+            for (int k = 0; k < 4; k++) {
+                const long long i = tbase + (r * SC_THREADS + tid) * 4 + k;
+                x[r][k] = i < n ? in[i] : 0;
+            }
     }
-    int sum = 0;
+    // what is summed: the value, or 1 per survivor
+    int sum[SC_ROUNDS], incl[SC_ROUNDS];
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) sum += v[k];
-    const int incl = wave_inclusive_scan(sum, lane);
-    if (lane == 63) wave_tot[wave] = incl;
+    for (int r = 0; r < SC_ROUNDS; r++) {
+        sum[r] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sum[r] += COMPACT ? (x[r][k] != 0 ? 1 : 0) : x[r][k];
+        incl[r] = wave_inclusive_scan(sum[r], lane);
+        if (lane == 63) s_wtot[r * SC_WAVES + wave] = incl[r];
+    }
     __syncthreads();
-    int wave_off = 0;
-    for (int w = 0; w < wave; w++) wave_off += wave_tot[w];
-    int run = wave_off + incl - sum;
-    int o[SC_ITEMS];
+
+    if (wave == 0) {
+        // the 64 (round, wave) totals are one wave's worth: scan them, then look back for what precedes the tile
+        static_assert(SC_ROUNDS * SC_WAVES == 64, "one lane per (round, wave) total");
+        const int t = s_wtot[lane];
+        const int ti = wave_inclusive_scan(t, lane);
+        s_wtot[lane] = ti - t;
+        const int total = __shfl(ti, 63);
+        int excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&status[0], ST_INCLUSIVE | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&status[tile], ST_AGGREGATE | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // lane l looks at tile j - l; every predecessor holds a ticket, so its word is only a matter of time
+            for (int j = tile - 1;; j -= 64) {
+                const int idx = j - lane;
+                int first, part;
+                for (;;) {
+                    const u64 st = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INCLUSIVE;
+                    const u64 inclusive = __ballot((st >> 32) == 2);
+                    const u64 pending = __ballot((st >> 32) == 0);
+                    first = inclusive ? __builtin_ctzll(inclusive) : 64;
+                    const u64 needed = first >= 63 ? ~0ull : ((2ull << first) - 1);       // lanes 0 .. first
+                    if ((pending & needed) == 0) { part = lane <= first ? (int)(unsigned)st : 0; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                excl += wave_sum(part);
+                if (first < 64) break;
+            }
+            if (lane == 0) __hip_atomic_store(&status[tile], ST_INCLUSIVE | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { s_excl = excl; s_total = total; }
+    }
+    __syncthreads();
+    const int excl = s_excl;
+    int off[SC_ROUNDS];
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) { o[k] = run; run += v[k]; }
-    if (base + SC_ITEMS <= n && ((((uintptr_t)(out + base)) & 15) == 0)) {
-        *reinterpret_cast<int4 *>(out + base) = make_int4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<int4 *>(out + base + 4) = make_int4(o[4], o[5], o[6], o[7]);
+    for (int r = 0; r < SC_ROUNDS; r++) off[r] = s_wtot[r * SC_WAVES + wave] + incl[r] - sum[r];
+
+    if (!COMPACT) {
+        if (whole && (((uintptr_t)out) & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < SC_ROUNDS; r++) {
+                int4 o;
+                o.x = excl + off[r]; o.y = o.x + x[r][0]; o.z = o.y + x[r][1]; o.w = o.z + x[r][2];
+                __builtin_nontemporal_store(v4i{o.x, o.y, o.z, o.w}, reinterpret_cast<v4i *>(out + tbase + (r * SC_THREADS + tid) * 4));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < SC_ROUNDS; r++) {
+                int run = excl + off[r];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long i = tbase + (r * SC_THREADS + tid) * 4 + k;
+                    if (i < n) out[i] = run;
+                    run += x[r][k];
+                }
+            }
+        }
     } else {
+        const int total = s_total;
 #pragma unroll
-        for (int k = 0; k < SC_ITEMS; k++) if (base + k < n) out[base + k] = o[k];
-    }
-    if (tid == SC_THREADS - 1) block_sums[blockIdx.x] = run;
-}
-
-// exclusive scan of the block totals, in place, by one workgroup with a running carry
-__global__ __launch_bounds__(1024) void k_sums_scan(int nblocks, int *__restrict__ sums) {
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + tid;
-        const int x = i < nblocks ? sums[i] : 0;
-        const int incl = wave_inclusive_scan(x, lane);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int off = carry_s;
-        for (int w = 0; w < wave; w++) off += wave_tot[w];
-        if (i < nblocks) sums[i] = off + incl - x;
-        __syncthreads();
-        if (tid == 1023) carry_s = off + incl;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(SC_THREADS) void k_add_offsets(int n, int *__restrict__ out, const int *__restrict__ sums) {
-    const int off = sums[blockIdx.x];
-    const long long base = (long long)blockIdx.x * SC_BLOCK + (long long)threadIdx.x * SC_ITEMS;
-    if (off == 0) return;
+        for (int r = 0; r < SC_ROUNDS; r++) {
+            int rank = off[r];
 #pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) if (base + k < n) out[base + k] += off;
-}
-
-// kernScatter (common.cu:40-49) with the boolean recomputed from the data; also publishes the count
-__global__ __launch_bounds__(SC_THREADS) void k_scatter(int n, int *__restrict__ out, const int *__restrict__ in,
-                                                         const int *__restrict__ indices, int *__restrict__ count) {
-    const int i = blockIdx.x * SC_THREADS + threadIdx.x;
-    if (i < n) {
-        const int x = in[i];
-        if (x != 0) out[indices[i]] = x;
-        if (i == n - 1) *count = indices[i] + (x != 0 ? 1 : 0);
+            for (int k = 0; k < 4; k++) if (x[r][k] != 0) s_stage[rank++] = x[r][k];
+        }
+        __syncthreads();
+        for (int i = tid; i < total; i += SC_THREADS) __builtin_nontemporal_store(s_stage[i], out + (long long)excl + i);
+        if (tid == 0 && tbase + SC_TILE >= n) *count = excl + total;
     }
 }
 
-int scan_device(int n, int *d_out, const int *d_in, int *d_sums, hipStream_t st, bool map) {
-    const int nblocks = (n + SC_BLOCK - 1) / SC_BLOCK;
-    if (map) hipLaunchKernelGGL(k_block_scan<true>, dim3(nblocks), dim3(SC_THREADS), 0, st, n, d_in, d_out, d_sums);
-    else hipLaunchKernelGGL(k_block_scan<false>, dim3(nblocks), dim3(SC_THREADS), 0, st, n, d_in, d_out, d_sums);
-    if (nblocks > 1) {
-        hipLaunchKernelGGL(k_sums_scan, dim3(1), dim3(1024), 0, st, nblocks, d_sums);
-        hipLaunchKernelGGL(k_add_offsets, dim3(nblocks), dim3(SC_THREADS), 0, st, n, d_out, d_sums);
-    }
+inline int sc_tiles(int n) { return (int)(((long long)n + SC_TILE - 1) / SC_TILE); }
+
+int onepass_device(int n, int *d_out, const int *d_in, int *d_count, void *d_ws, hipStream_t st, bool compact) {
+    const int ntiles = sc_tiles(n);
+    unsigned *ticket = (unsigned *)d_ws;
+    u64 *status = (u64 *)((char *)d_ws + SC_HEAD);
+    SC_CHECK(hipMemsetAsync(d_ws, 0, SC_HEAD + sizeof(u64) * (size_t)ntiles, st));
+    if (compact) hipLaunchKernelGGL((k_onepass<true, SC_COMPACT_THREADS>), dim3(ntiles), dim3(SC_COMPACT_THREADS), 0, st, n, d_in, d_out, ticket, status, d_count);
+    else hipLaunchKernelGGL((k_onepass<false, SC_SCAN_THREADS>), dim3(ntiles), dim3(SC_SCAN_THREADS), 0, st, n, d_in, d_out, ticket, status, d_count);
     SC_CHECK(hipGetLastError());
     return PTX_OK;
 }
@@ -150,7 +211,7 @@ int host_scan(int n, int *odata, const int *idata) {
     SC_CHECK(hipMemcpy(d_in, idata, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     SC_CHECK(hipEventCreate(&e0)); SC_CHECK(hipEventCreate(&e1));
     SC_CHECK(hipEventRecord(e0, 0));
-    int rc = scan_device(n, d_out, d_in, d_ws, 0, false);
+    int rc = onepass_device(n, d_out, d_in, nullptr, d_ws, 0, false);
     SC_CHECK(hipEventRecord(e1, 0));
     SC_CHECK(hipEventSynchronize(e1));
     SC_CHECK(hipEventElapsedTime(&g_gpu_ms, e0, e1));
@@ -244,31 +305,25 @@ int sc_efficient_compact(int n, int *odata, const int *idata) {
 }
 
 unsigned long long sc_scan_workspace_bytes(int n) {
-    // block totals + (for compaction) the index array
-    const unsigned long long nblocks = n > 0 ? ((unsigned long long)n + SC_BLOCK - 1) / SC_BLOCK : 1;
-    const unsigned long long head = (nblocks + 16 + 3) & ~3ull;          // keeps the index array 16-byte aligned
-    return sizeof(int) * (head + (unsigned long long)(n > 0 ? n : 0));
+    // the ticket counter and one status word per tile; the workspace must be 8-byte aligned (any hipMalloc is)
+    return SC_HEAD + sizeof(u64) * (unsigned long long)(n > 0 ? sc_tiles(n) : 1);
 }
 
 int sc_scan_device(int n, int *d_odata, const int *d_idata, void *d_workspace, void *stream) {
     if (n <= 0) return PTX_OK;
     if (!d_odata || !d_idata || !d_workspace) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
-    return scan_device(n, d_odata, d_idata, (int *)d_workspace, (hipStream_t)stream, false);
+    if (((uintptr_t)d_workspace) & 7) { ptx_internal_set_error("workspace must be 8-byte aligned"); return PTX_ERR_INVALID; }
+    return onepass_device(n, d_odata, d_idata, nullptr, d_workspace, (hipStream_t)stream, false);
 }
 
+// d_odata must not alias d_idata: a tile's survivors land where an earlier position's tile may still be reading
 int sc_compact_device(int n, int *d_odata, const int *d_idata, int *d_count, void *d_workspace, void *stream) {
     if (!d_count) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     if (n <= 0) { SC_CHECK(hipMemsetAsync(d_count, 0, sizeof(int), st)); return PTX_OK; }
     if (!d_odata || !d_idata || !d_workspace) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
-    const int nblocks = (n + SC_BLOCK - 1) / SC_BLOCK;
-    int *d_sums = (int *)d_workspace;
-    int *d_indices = d_sums + ((nblocks + 16 + 3) & ~3);
-    int rc = scan_device(n, d_indices, d_idata, d_sums, st, true);
-    if (rc != PTX_OK) return rc;
-    hipLaunchKernelGGL(k_scatter, dim3((n + SC_THREADS - 1) / SC_THREADS), dim3(SC_THREADS), 0, st, n, d_odata, d_idata, d_indices, d_count);
-    SC_CHECK(hipGetLastError());
-    return PTX_OK;
+    if (((uintptr_t)d_workspace) & 7) { ptx_internal_set_error("workspace must be 8-byte aligned"); return PTX_ERR_INVALID; }
+    return onepass_device(n, d_odata, d_idata, d_count, d_workspace, st, true);
 }
 
 float sc_last_gpu_ms(void) { return g_gpu_ms; }

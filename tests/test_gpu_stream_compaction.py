@@ -45,3 +45,67 @@ def test_live_flag_arrays_of_config4(gpu_product):
         flags[rng.choice(n, live, replace=False)] = rng.integers(1, 8, live)
         out = sc.efficient_compact(flags)
         assert len(out) == live and np.array_equal(out, flags[flags != 0])
+
+
+@pytest.mark.parametrize("n", [1, 16383, 16384, 16385, 64 * 16384 + 1, 65 * 16384, 1920 * 1080, 3840 * 2160, (1 << 26) + 3])
+def test_device_pointer_forms(gpu_product, n):
+    """sc_scan_device / sc_compact_device on buffers already in HBM (torch only holds the memory): every tile count around
+    the look-back window of 64, unaligned views (pointer + 4 bytes), in-place scan, a side stream, repeated use of one
+    workspace; integer-exact against numpy."""
+    import torch
+    sc = gpu_product.StreamCompaction()
+    rng = np.random.default_rng(n)
+    a = (rng.integers(-4, 9, n) * (rng.random(n) < 0.4)).astype(np.int32)
+    want_scan = np.concatenate([[0], np.cumsum(a, dtype=np.int64)[:-1]]).astype(np.int32)
+    want_keep = a[a != 0]
+    dev = torch.device("cuda", 0)
+    buf_in = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    buf_out = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    ws = torch.zeros((sc.workspace_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    host = torch.from_numpy(a)
+    for shift in (0, 1):                                    # shift 1: 4-byte-aligned only -> the scalar load/store path
+        d_in, d_out = buf_in[shift:shift + n], buf_out[shift:shift + n]
+        d_in.copy_(host)
+        torch.cuda.synchronize()
+        for stream in (0, side.cuda_stream):
+            d_out.zero_(); torch.cuda.synchronize()
+            sc.scan_device(n, d_out.data_ptr(), d_in.data_ptr(), ws.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), want_scan)
+            d_out.fill_(-77); torch.cuda.synchronize()
+            sc.compact_device(n, d_out.data_ptr(), d_in.data_ptr(), count.data_ptr(), ws.data_ptr(), stream)
+            torch.cuda.synchronize()
+            k = int(count.item())
+            assert k == len(want_keep)
+            got = d_out.cpu().numpy()
+            assert np.array_equal(got[:k], want_keep) and np.all(got[k:] == -77)      # nothing written past the survivors
+        sc.scan_device(n, d_in.data_ptr(), d_in.data_ptr(), ws.data_ptr(), 0)         # in place
+        torch.cuda.synchronize()
+        assert np.array_equal(d_in.cpu().numpy(), want_scan)
+
+
+def test_device_forms_degenerate(gpu_product):
+    import torch
+    sc = gpu_product.StreamCompaction()
+    dev = torch.device("cuda", 0)
+    count = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    ws = torch.zeros(16, dtype=torch.int64, device=dev)
+    sc.compact_device(0, 0, 0, count.data_ptr(), ws.data_ptr())          # n = 0: count := 0, nothing else touched
+    torch.cuda.synchronize()
+    assert int(count.item()) == 0
+    sc.scan_device(0, 0, 0, 0)
+    with pytest.raises(gpu_product.PathTracerError):
+        sc.scan_device(8, 0, 0, 0)
+    with pytest.raises(gpu_product.PathTracerError):
+        sc.scan_device(8, ws.data_ptr(), ws.data_ptr(), ws.data_ptr() + 4)   # misaligned workspace
+    ones = torch.ones(1 << 22, dtype=torch.int32, device=dev)               # every element survives, prefix = index
+    out = torch.zeros_like(ones)
+    big_ws = torch.zeros((sc.workspace_bytes(1 << 22) + 7) // 8, dtype=torch.int64, device=dev)
+    sc.scan_device(1 << 22, out.data_ptr(), ones.data_ptr(), big_ws.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.arange(1 << 22, dtype=torch.int32, device=dev))
+    sc.compact_device(1 << 22, out.data_ptr(), ones.data_ptr(), count.data_ptr(), big_ws.data_ptr())
+    torch.cuda.synchronize()
+    assert int(count.item()) == 1 << 22 and bool((out == 1).all())
