@@ -663,6 +663,40 @@ def test_random_scenes_on_the_tile_path(gpu_product, O, tmp_path, seed):
     _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
 
 
+def test_large_scene_beyond_the_fast_path_limits(gpu_product, O, tmp_path):
+    """A scene past every limit of the fast path -- 70 geoms (> 32: no candidate masks), four BVH meshes (> 2: the mesh
+    search stays inside the bounce kernel), 45 materials (45 sort bins) -- takes the general code automatically and
+    still equals the oracle bit for bit; so does the same scene with the mesh tree switched off."""
+    rng = np.random.default_rng(4242)
+    kinds = [(1, 1, 1, 0, 0, 0, 0, 0, 0, 5)]
+    for m in range(1, 45):
+        c = tuple(np.round(rng.uniform(0.2, 0.95, 3), 3))
+        r = rng.random()
+        kinds.append(c + ((.9, .9, .9, 1, 0, 0, 0) if r < 0.15 else (.9, .9, .9, 0, 1, 1.4, 0) if r < 0.3 else (0, 0, 0, 0, 0, 0, 0)))
+    text = "".join(MAT % ((m,) + kinds[m]) for m in range(len(kinds))) + CAMERA_BLOCK
+    objs = ["cube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 4 .3 4", "cube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 11 .01 11",
+            "cube\nmaterial 2\nTRANS 0 10 0\nROTAT 0 0 90\nSCALE .01 11 11", "cube\nmaterial 3\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 11 11",
+            "cube\nmaterial 4\nTRANS -5 5 0\nROTAT 0 0 0\nSCALE .01 11 11", "cube\nmaterial 5\nTRANS 5 5 0\nROTAT 0 0 0\nSCALE .01 11 11"]
+    ships = {7, 21, 40, 63}
+    for k in range(6, 70):
+        pos = rng.uniform([-4.0, 0.6, -4.0], [4.0, 8.5, 3.0])
+        rot = rng.uniform(-180, 180, 3)
+        sc = rng.uniform(0.3, 1.2, 3)
+        if k in ships:
+            head = "obj\n../models/standin_ship.obj"
+        elif k % 9 == 0:
+            head = "obj\n../models/cube.obj"
+        else:
+            head = ("sphere" if k % 2 else "cube") + "\nmaterial %d" % int(rng.integers(1, len(kinds)))
+        objs.append(head + "\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g" % (tuple(pos) + tuple(rot) + tuple(sc)))
+    text += "".join("OBJECT %d\n%s\n\n" % (i, o) for i, o in enumerate(objs))
+    s = _scene_from_text(gpu_product, text, tmp_path, res=(96, 64), depth=6)
+    assert s.num_geoms == 70 and s.num_materials >= 45
+    a = _vs_oracle(gpu_product, O, s, iters=2)
+    b = _vs_oracle(gpu_product, O, s, iters=2, no_bvh=1, batch=1)
+    assert beq(a, b)
+
+
 def test_png_rgba_maps_render_like_the_oracle(gpu_product, O, tmp_path):
     """The stand-in ship with its four maps as 4-channel PNGs (texel stride 4, alpha ignored as in the reference's
     image[(..) * channels + c]): loader -> HIP tracer equals loader -> oracle, and equals the PPM version of the scene
