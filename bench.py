@@ -47,6 +47,20 @@ def cpu_baseline(scene, iters):
         rays += int(O.live_counts().sum())
     dt = time.time() - t0
     sec = O.stage_seconds()
+    # the same port with its two per-path loops (intersect, shade) on every core the process may use;
+    # sort, partition and gather stay serial.  Same results (tests/test_oracle_golden.py), clearly not the 1-thread figure.
+    ncores = len(os.sched_getaffinity(0))
+    all_cores = None
+    if ncores > 1:
+        O.set_threads(ncores)
+        t1 = time.time()
+        mrays = 0
+        for it in range(iters + 1, 3 * iters + 1):
+            O.iterate(it)
+            mrays += int(O.live_counts().sum())
+        mdt = time.time() - t1
+        O.set_threads(1)
+        all_cores = dict(value=mrays / mdt / 1e6, unit="Mrays/s", cores=ncores, sample="%d iterations, %.1f s, OpenMP over the paths of the intersect and shade stages" % (2 * iters, mdt))
     # StreamCompaction::CPU (stream_compaction/cpu.cu:20-95) on the per-bounce "still alive" flag arrays
     # of one iteration, timed alone, next to the library's GPU compaction of the same arrays (host pointers in and out)
     import numpy as np
@@ -103,7 +117,7 @@ def cpu_baseline(scene, iters):
                              sample="3 iterations, %.1f s, the reference's intersections.h / interactions.h built host-only (oracle/_ref)" % rdt)
         except Exception as e:                      # the baseline is optional, the bench line is not
             reference = dict(error=str(e)[:200])
-    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port", reference=reference,
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port", reference=reference, all_cores=all_cores,
                 stream_compaction_ms_per_iteration=dict(elements=sum(counts), **ms),
                 sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))

@@ -53,6 +53,12 @@ static inline v3 multiplyMV(const float *m, v3 v, float w) {
 /* libm switch                                                                                              */
 static int g_libm_mode = 0;
 void o_set_libm(int mode) { g_libm_mode = mode; }
+
+/* Threads for the two per-path loops (intersect, shade) of o_pt_bounce: the paths of a stage are independent, so the
+ * results do not depend on it.  1 (the default) is the single-thread baseline; > 1 is bench.py's clearly labelled
+ * all-cores figure.  The sort, the partition and the gather stay serial. */
+static int g_threads = 1;
+void o_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int o_get_libm(void) { return g_libm_mode; }
 
 /* Portable sin/cos for float arguments: Cody-Waite reduction by pi/2 and Taylor polynomials, all in binary64
@@ -908,6 +914,7 @@ int o_pt_bounce(void *h, int iter, int stage_mask) {
             if (s->opt_sort) sort_by_material(s, s->pixelcount);
         }
         memset(s->isects, 0, sizeof(o_isect) * (size_t)s->pixelcount);           /* :501 */
+        _Pragma("omp parallel for schedule(dynamic, 2048) num_threads(g_threads) if (g_threads > 1)")
         for (int i = 0; i < num_paths; i++) compute_intersection_one(s, &s->paths[i], &s->isects[i]);
         if (cache_compiled && iter == 1 && s->depth == 0)
             memcpy(s->first_isects, s->isects, sizeof(o_isect) * (size_t)s->pixelcount);
@@ -954,6 +961,7 @@ int o_pt_bounce(void *h, int iter, int stage_mask) {
                 }
             }
         }
+        _Pragma("omp parallel for schedule(dynamic, 2048) num_threads(g_threads) if (g_threads > 1)")
         for (int i = 0; i < num_paths; i++) shade_one(s, iter, i, &s->isects[i], &s->paths[i]);
         s->secs[2] += now_s() - t0;
     }

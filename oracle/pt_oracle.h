@@ -41,6 +41,7 @@ typedef struct {
     int geomId;
 } o_isect;
 
+void o_set_threads(int n);           /* threads of the per-path loops (results do not depend on it); default 1 */
 void o_set_libm(int mode);            /* 0 = glibc (reference host semantics), 1 = portable own routines */
 int o_get_libm(void);
 

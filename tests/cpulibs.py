@@ -274,6 +274,7 @@ class OracleLib(_Tracer):
         L = self.lib
         i, f = C.c_int, C.c_float
         L.o_set_libm.argtypes = [i]
+        L.o_set_threads.argtypes = [i]
         L.o_get_libm.restype = i
         L.o_own_sincosf.argtypes = [f, vp, vp]
         L.o_own_pow5.restype, L.o_own_pow5.argtypes = C.c_double, [C.c_double]
@@ -298,6 +299,9 @@ class OracleLib(_Tracer):
 
     def set_libm(self, mode):
         self.lib.o_set_libm(mode)
+
+    def set_threads(self, n):
+        self.lib.o_set_threads(int(n))
 
     def create(self, dump, textures=None):
         """dump: dict as produced by RefLib.dump() or the product loader; textures: {(geom, which): HxWxC uint8}."""

@@ -149,6 +149,21 @@ def test_full_renders(O, tag):
     assert beq(O.pbo(16), r["pbo_spp16"])
 
 
+@pytest.mark.parametrize("tag", ["c4_obj", "c5_ship"])
+def test_threads_do_not_change_the_oracle(O, tag):
+    """o_set_threads(4) (bench.py's all-cores baseline: the intersect and shade loops under OpenMP) against the golden
+    image and counts of the single-thread run: the paths of a stage are independent, so the bits are the same."""
+    r = oracle_for_render(O, tag)
+    O.set_threads(4)
+    try:
+        for it in range(1, 3):
+            O.iterate(it)
+        assert beq(O.live_counts(), r["counts_it2"])
+        assert beq(O.image(), r["image_spp2"])
+    finally:
+        O.set_threads(1)
+
+
 def test_c1_plumbing_cpu_stream_compaction(O):
     """BASELINE config 1: sphere.txt 256x256 depth 4, 1 spp on the CPU path whose dead-ray compaction is the
     StreamCompaction::CPU scan+scatter (oracle partition_paths); counts and radiance as the reference gives."""
