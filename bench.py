@@ -31,6 +31,27 @@ BYTES_BOUNCE_KERNEL = 76 + 120
 BYTES_LOOP = 436
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a GPU box
+    shows all 256 host cores but grants a share of them), and to 16 -- the share of a one-GPU box -- when the quota cannot
+    be read."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    return max(1, min(n, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    return max(1, min(n, int(quota / period + 0.5)))
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, 16)
+
+
 def cpu_baseline(scene, iters):
     """Single-thread CPU oracle on a bounded sample of the same workload (checker code, timed here as a baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -49,7 +70,7 @@ def cpu_baseline(scene, iters):
     sec = O.stage_seconds()
     # the same port with its two per-path loops (intersect, shade) on every core the process may use;
     # sort, partition and gather stay serial.  Same results (tests/test_oracle_golden.py), clearly not the 1-thread figure.
-    ncores = len(os.sched_getaffinity(0))
+    ncores = usable_cores()
     all_cores = None
     if ncores > 1:
         O.set_threads(ncores)
