@@ -92,7 +92,9 @@ struct Decoder {
                 while (c == 0xff) c = get8();
                 if (c != 0) { marker = c; nomore = true; return; }
             }
-            buf |= b << (24 - nbits);
+            // nbits can be negative once a marker has ended the data (a read took more bits than were left); b is 0 from
+            // then on, so the out-of-range shift stb performs there contributes nothing: skip it instead (tools/fuzz, UBSan)
+            if (nbits >= -7) buf |= b << (24 - nbits);
             nbits += 8;
         } while (nbits <= 24);
     }
@@ -389,6 +391,10 @@ struct Decoder {
         if ((uint64_t)img_x * img_y > (1u << 27)) return false;        // bounds the working memory (pt_png.h uses the same limit)
         h_max = v_max = 1;
         for (int i = 0; i < img_n; i++) { if (comp[i].h > h_max) h_max = comp[i].h; if (comp[i].v > v_max) v_max = comp[i].v; }
+        // sampling factors that do not divide the largest one: the vendored stb_image then upsamples by the truncated ratio
+        // and reads past the component's rows and, on the last row, past its buffer (later stb versions refuse such
+        // files as corrupt) -- nothing defined to be identical to, so "failed to load" (found by tools/fuzz)
+        for (int i = 0; i < img_n; i++) if (h_max % comp[i].h || v_max % comp[i].v) return false;
         const int mcu_w = h_max * 8, mcu_h = v_max * 8;
         mcu_x = (img_x + mcu_w - 1) / mcu_w;
         mcu_y = (img_y + mcu_h - 1) / mcu_h;
