@@ -164,6 +164,13 @@ int ptx_reset_image(ptx_tracer *t);
 /* One iteration of pathtrace() (iter is 1-based and seeds the RNG).  Enqueues on the tracer's stream and
  * returns without waiting; any read entry point below synchronises. */
 int ptx_iterate(ptx_tracer *t, int iter);
+/* Render-ahead for callers that keep the reference's shape -- one pathtrace(iter) per call, iter counting up
+ * (src/main.cpp:128-148).  on != 0: ptx_iterate traces the next batch of iterations in the background (other streams,
+ * per-iteration radiance buffers) and each call adds exactly its own iteration to the image, so what every call returns
+ * -- image, statistics, preview -- is unchanged bit for bit, at the cost per iteration of ptx_render.  A camera change,
+ * a jump in iter or any other render call simply drops what was traced ahead.  Off by default in this ABI; the C++ veneer
+ * (pathtrace_api.h) switches it on.  Needs the default launch-set layout (lanes >= 3, batch > 1); otherwise it is a no-op. */
+int ptx_set_render_ahead(ptx_tracer *t, int on);
 /* iterations iter_first .. iter_first+count-1 back to back, no host round trip in between */
 int ptx_render(ptx_tracer *t, int iter_first, int count);
 /* iterations iter_first, iter_first+stride, ... (count of them): N ranks that take turns over the iterations of one

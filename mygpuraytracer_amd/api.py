@@ -148,6 +148,7 @@ def load_library():
     L.ptx_set_camera.restype, L.ptx_set_camera.argtypes = i, [vp, C.POINTER(Camera), i]
     L.ptx_reset_image.restype, L.ptx_reset_image.argtypes = i, [vp]
     L.ptx_iterate.restype, L.ptx_iterate.argtypes = i, [vp, i]
+    L.ptx_set_render_ahead.restype, L.ptx_set_render_ahead.argtypes = i, [vp, i]
     L.ptx_render.restype, L.ptx_render.argtypes = i, [vp, i, i]
     L.ptx_render_strided.restype, L.ptx_render_strided.argtypes = i, [vp, i, i, i]
     L.ptx_write_image.restype, L.ptx_write_image.argtypes = i, [vp, vp]
@@ -368,6 +369,10 @@ class Tracer:
         _check(self.lib.ptx_iterate(self.h, iteration), "ptx_iterate")
         self.iteration = iteration
         return self.read_image() if read_image else None
+
+    def set_render_ahead(self, on=True):
+        """ptx_set_render_ahead: iterate() calls that count up are served from batches traced in the background"""
+        _check(self.lib.ptx_set_render_ahead(self.h, 1 if on else 0), "ptx_set_render_ahead")
 
     def render(self, iter_first, count, stride=1):
         """iterations iter_first, iter_first + stride, ... (count of them), no host round trip in between"""

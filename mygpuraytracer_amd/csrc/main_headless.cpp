@@ -7,6 +7,8 @@
 //                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
 //                                  [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]
 //                                  [--orbit "left:DX,DY;right:DY;middle:DX,DY;space"]   (the mouse of main.cpp:166-212, scripted)
+//                                  [--per-call [--no-render-ahead]]   (one pathtrace(pbo, frame, iter) per iteration with the frame read
+//                                                                      back after each, exactly the reference's runCuda loop)
 //
 // RES / DEPTH / ITERATIONS overrides and the four switches are what the reference can only change by editing the
 // scene file or the #defines of src/pathtrace.cu:36-40.
@@ -33,11 +35,11 @@ static std::string currentTimeString() {          // src/preview.cpp:13-19
 int main(int argc, char **argv) {
     const std::string startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT] [--per-call [--no-render-ahead]]\n", argv[0]);
         return 1;
     }
     int resw = 0, resh = 0, depth = 0, iterations = 0;
-    bool pfm = false, hdr = false;
+    bool pfm = false, hdr = false, per_call = false;
     std::string out_prefix, ckpt_path, resume_path, orbit_script;
     int ckpt_every = 0;
     ptx_options &opt = pathtraceOptions();
@@ -59,6 +61,8 @@ int main(int argc, char **argv) {
         else if (a == "--dof") opt.depth_of_field = 1;
         else if (a == "--no-sort") opt.sort_by_material = 0;
         else if (a == "--no-cache") opt.cache_first_bounce = 0;
+        else if (a == "--per-call") per_call = true;
+        else if (a == "--no-render-ahead") pathtraceRenderAhead() = false;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     Scene *scene = nullptr;
@@ -90,6 +94,16 @@ int main(int argc, char **argv) {
     }
     const int rendered = std::max(n - done, 0);
     const int chunk = (!ckpt_path.empty() && ckpt_every > 0) ? ckpt_every : n;
+    double per_call_ms = 0.0;
+    if (per_call) {
+        // the reference's own loop (runCuda, src/main.cpp:128-148): one pathtrace(pbo, frame, iteration) per frame, the fp32 frame
+        // in state.image after each, the timer summed per call.  No window, so no PBO.
+        for (int it = done + 1; it <= n; it++) {
+            pathtrace(nullptr, 0, it);
+            per_call_ms += timer().getGpuElapsedTimeForPreviousOperation();
+        }
+        done = n;
+    }
     while (done < n) {
         const int count = std::min(chunk, n - done);
         if (ptx_render(t, done + 1, count) != PTX_OK || ptx_read_image(t, &scene->state.image[0].x) != PTX_OK) {
@@ -103,7 +117,7 @@ int main(int argc, char **argv) {
     }
     ptx_stats st;
     ptx_get_stats(t, &st);
-    printf("time: %g\n", st.loop_ms_total);                                             // main.cpp:146
+    printf("time: %g\n", per_call ? per_call_ms : st.loop_ms_total);                    // main.cpp:146
     if (rendered > 0)
         printf("%d x %d, depth %d, %d samples (%d traced now): %.3f ms/iteration, %.1f Mrays/s\n", width, height, scene->state.traceDepth, n,
                rendered, st.loop_ms_total / rendered, st.rays_total / (st.loop_ms_total * 1e-3) / 1e6);

@@ -81,6 +81,11 @@ ptx_options &pathtraceOptions() {
     return g_options;
 }
 
+bool &pathtraceRenderAhead() {
+    static bool on = true;
+    return on;
+}
+
 PerformanceTimer &timer() {
     static PerformanceTimer t;
     return t;
@@ -93,6 +98,7 @@ void pathtraceInit(Scene *scene) {
     check(ptx_create((int)scene->geoms.size(), scene->geoms.data(), (int)scene->materials.size(), scene->materials.data(),
                      &scene->state.camera, scene->state.traceDepth, &pathtraceOptions(), nullptr, nullptr, &g_tracer),
           "pathtraceInit");
+    check(ptx_set_render_ahead(g_tracer, pathtraceRenderAhead() ? 1 : 0), "pathtraceInit");
 }
 
 void pathtraceFree() {          // safe before init and idempotent, as main.cpp:129 relies on

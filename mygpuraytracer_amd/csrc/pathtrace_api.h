@@ -64,6 +64,8 @@ public:
 
 // Runtime form of the #defines in src/pathtrace.cu:36-40; read by the next pathtraceInit.
 ptx_options &pathtraceOptions();
+bool &pathtraceRenderAhead();                           // true (default): pathtrace(iter) calls that count up are served from
+                                                        // iterations traced ahead in the background (ptx_set_render_ahead); same results
 
 PerformanceTimer &timer();                              // src/pathtrace.h:6
 void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7

@@ -997,7 +997,18 @@ struct ptx_tracer {
                                                          // kmax segments of every per-iteration buffer (lane 0 = `stream`)
     hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] = `stream`, the others are the tracer's own
     hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_chain[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    // Render-ahead for the one-iteration-per-call shape (ptx_iterate = the reference's pathtrace(iter)): lanes 1 and 2 take
+    // turns tracing the NEXT kmax iterations into their per-iteration radiance buffers while the caller works the current
+    // batch off, one k_gather (+ k_stats) per call on the main stream.  What a call returns is unchanged: the image holds
+    // exactly the iterations asked for so far, summed in the same order.
+    struct Ahead { int first = 0, count = 0, next = 0, unfolded = 0; bool use_cache = false, valid = false, timed = false; };
+    Ahead ahead[MAX_LANES];
+    int ahead_cur = -1, ahead_nxt = -1;                  // lane whose batch is being consumed / lane holding the batch after it
+    bool render_ahead = false;
+    int last_ahead_lane = -1;                            // != -1: the previous operation was a call served from that lane's batch
+    hipEvent_t ev_ahead0[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_ahead1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     int uses_uv = 0;
+    uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
     unsigned long long *d_stamps = nullptr;              // diagnostic build only
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
@@ -1093,11 +1104,12 @@ int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
+    for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamSynchronize(t->lane_stream[l]);      // work traced ahead
     hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
-    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps); hipFree(t->d_pbo);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
@@ -1105,6 +1117,8 @@ int free_tracer(ptx_tracer *t) {
     if (t->ev_fork) hipEventDestroy(t->ev_fork);
     for (hipEvent_t e : t->ev_join) if (e) hipEventDestroy(e);
     for (hipEvent_t e : t->ev_chain) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : t->ev_ahead0) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : t->ev_ahead1) if (e) hipEventDestroy(e);
     if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
     delete t;
     return PTX_OK;
@@ -1116,7 +1130,7 @@ int free_tracer(ptx_tracer *t) {
 // Lane `lane` works on segments lane*kmax .. of every per-iteration buffer and on its own stream; the image is touched
 // only by k_gather, and the gathers of successive batches are chained by events (prev_lane = the lane the previous batch
 // ran on), so the fp32 sums happen in iteration order whatever the overlap.
-int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane = 0, int prev_lane = -1) {
+int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane = 0, int prev_lane = -1, bool defer = false) {
     hipStream_t stream = lane == 0 ? t->stream : t->lane_stream[lane];
     const size_t seg0 = (size_t)lane * t->kmax;
     const int nb = t->nbins;
@@ -1255,6 +1269,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             t->cap_filled = true;
         }
     }
+    if (defer) {                                     // render-ahead: gather and statistics follow per iteration (finish_segment)
+        t->ahead[lane].use_cache = use_cache;
+        HIPCHECK(hipGetLastError());
+        return PTX_OK;
+    }
     if (prev_lane >= 0 && prev_lane != lane) HIPCHECK(hipStreamWaitEvent(stream, t->ev_chain[prev_lane], 0));      // the previous batch's gather + stats
     if (batched)
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
@@ -1265,6 +1284,62 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     HIPCHECK(hipGetLastError());
     t->iterations += K;
     (void)nsuper;
+    return PTX_OK;
+}
+
+// ---- render-ahead (ptx_iterate) ---------------------------------------------------------------------------------------
+// adds the time of the lane's batch, in proportion to the iterations that were taken from it, to the running total
+void ahead_fold_time(ptx_tracer *t, int lane) {
+    ptx_tracer::Ahead &a = t->ahead[lane];
+    if (!a.timed || !a.unfolded || !a.count) { a.unfolded = 0; return; }
+    float ms = 0.f;
+    if (hipEventSynchronize(t->ev_ahead1[lane]) == hipSuccess && hipEventElapsedTime(&ms, t->ev_ahead0[lane], t->ev_ahead1[lane]) == hipSuccess)
+        t->loop_ms_total += (double)ms * a.unfolded / a.count;
+    a.unfolded = 0;
+}
+
+// forgets what was traced ahead (camera changed, another kind of call came in, the sequence jumped)
+void ahead_discard(ptx_tracer *t) {
+    for (int l = 1; l < MAX_LANES; l++) {
+        if (t->ahead[l].valid || t->ahead[l].unfolded) ahead_fold_time(t, l);
+        t->ahead[l].valid = false;
+    }
+    t->ahead_cur = t->ahead_nxt = -1;
+    t->last_ahead_lane = -1;
+}
+
+bool ahead_possible(const ptx_tracer *t, int iter) {
+    if (!t->render_ahead || t->lanes < 3 || t->kmax < 2 || t->ktiming || t->capture_bounce >= 0) return false;
+    if (t->cache_active() && (!t->cache_valid || iter == 1)) return false;       // that call fills the first-bounce cache
+    return true;
+}
+
+// traces iterations first .. first + kmax - 1 on `lane`, gathers nothing yet
+int ahead_start(ptx_tracer *t, int lane, int first) {
+    hipStream_t ls = t->lane_stream[lane];
+    ahead_fold_time(t, lane);                            // the events are about to be re-recorded
+    HIPCHECK(hipEventRecord(t->ev_fork, t->stream));     // after everything on the main stream so far: the cache fill, and the
+    HIPCHECK(hipStreamWaitEvent(ls, t->ev_fork, 0));     // gathers that still read this lane's buffers
+    HIPCHECK(hipEventRecord(t->ev_ahead0[lane], ls));
+    int rc = enqueue_batch(t, first, t->kmax, 1, lane, -1, true);
+    if (rc != PTX_OK) return rc;
+    HIPCHECK(hipEventRecord(t->ev_ahead1[lane], ls));
+    ptx_tracer::Ahead &a = t->ahead[lane];
+    a.first = first; a.count = t->kmax; a.next = first; a.unfolded = 0; a.valid = true; a.timed = true;
+    return PTX_OK;
+}
+
+// one iteration of a traced-ahead batch into the image: what the tail of enqueue_batch does for a whole batch
+int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
+    const ptx_tracer::Ahead &a = t->ahead[lane];
+    const size_t sg = (size_t)lane * t->kmax + seg, seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
+    HIPCHECK(hipStreamWaitEvent(t->stream, t->ev_ahead1[lane], 0));
+    hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, 1,
+                       seg_part, t->d_part + sg * seg_part, t->d_image);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals + sg * t->seg_totals, t->nbins, t->traceDepth, 2 * t->nbins,
+                       a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64);
+    HIPCHECK(hipGetLastError());
+    t->iterations += 1;
     return PTX_OK;
 }
 
@@ -1512,6 +1587,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             if (l) HC(hipStreamCreateWithFlags(&t->lane_stream[l], hipStreamNonBlocking));
             HC(hipEventCreateWithFlags(&t->ev_join[l], hipEventDisableTiming));
             HC(hipEventCreateWithFlags(&t->ev_chain[l], hipEventDisableTiming));
+            if (l) { HC(hipEventCreate(&t->ev_ahead0[l])); HC(hipEventCreate(&t->ev_ahead1[l])); }
         }
     }
     const size_t nseg = (size_t)kmax * t->lanes;
@@ -1578,8 +1654,16 @@ int ptx_set_camera(ptx_tracer *t, const ptx_camera *camera, int trace_depth) {
     if (camera->resolution[0] != t->cam.resx || camera->resolution[1] != t->cam.resy)
         return set_error(PTX_ERR_INVALID, "resolution is fixed at create (buffer sizes, src/pathtrace.cu:104-109)");
     if (trace_depth < 1 || trace_depth > t->maxBounces) return set_error(PTX_ERR_INVALID, "trace depth exceeds the depth given at create");
+    {   // the reference-shaped loop sets the camera before every iteration (src/pathtrace.cu:434-436): the same values
+        // again change nothing, so neither the first-bounce cache nor what was traced ahead is thrown away
+        DCamera same;
+        memcpy(&same, &t->cam, sizeof same);
+        camera_to_device(*camera, same);
+        if (trace_depth == t->traceDepth && memcmp(&same, &t->cam, sizeof same) == 0) return PTX_OK;
+    }
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
+    ahead_discard(t);
     camera_to_device(*camera, t->cam);
     t->traceDepth = trace_depth;
     t->cache_valid = false;
@@ -1602,6 +1686,7 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     if (stride < 1) return set_error(PTX_ERR_INVALID, "ptx_render_strided: stride must be >= 1");
     if (count <= 0) return PTX_OK;
     HIPCHECK(hipSetDevice(t->device));
+    ahead_discard(t);
     if (t->timing_valid) {          // fold the previous batch's time into the running total before reusing events
         float ms = 0.f;
         HIPCHECK(hipEventSynchronize(t->ev_stop));
@@ -1654,7 +1739,51 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     return PTX_OK;
 }
 
-int ptx_iterate(ptx_tracer *t, int iter) { return ptx_render(t, iter, 1); }
+int ptx_set_render_ahead(ptx_tracer *t, int on) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    if (!on) ahead_discard(t);
+    t->render_ahead = on != 0;
+    return PTX_OK;
+}
+
+int ptx_iterate(ptx_tracer *t, int iter) {
+    if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
+    if (!ahead_possible(t, iter)) return ptx_render(t, iter, 1);
+    HIPCHECK(hipSetDevice(t->device));
+    if (t->ahead_cur < 0 || !t->ahead[t->ahead_cur].valid || t->ahead[t->ahead_cur].next != iter) {
+        // nothing traced ahead for this iteration (first call, or the sequence jumped): start at it
+        ahead_discard(t);
+        if (t->timing_valid) {      // the previous ptx_render's time, before "previous operation" becomes this call
+            float ms = 0.f;
+            HIPCHECK(hipEventSynchronize(t->ev_stop));
+            HIPCHECK(hipEventElapsedTime(&ms, t->ev_start, t->ev_stop));
+            t->loop_ms_total += ms;
+            t->timing_valid = false;
+        }
+        int rc = ahead_start(t, 1, iter);
+        if (rc != PTX_OK) return rc;
+        t->ahead_cur = 1;
+    }
+    const int lane = t->ahead_cur;
+    ptx_tracer::Ahead &a = t->ahead[lane];
+    // keep one batch ahead of the one being consumed, on the other lane
+    if (t->ahead_nxt < 0) {
+        const int other = lane == 1 ? 2 : 1;
+        int rc = ahead_start(t, other, a.first + a.count);
+        if (rc != PTX_OK) return rc;
+        t->ahead_nxt = other;
+    }
+    int rc = ahead_finish_segment(t, lane, iter - a.first);
+    if (rc != PTX_OK) return rc;
+    a.next++; a.unfolded++;
+    t->last_ahead_lane = lane;
+    if (a.next == a.first + a.count) {                   // used up: on to the batch traced meanwhile
+        a.valid = false;
+        t->ahead_cur = t->ahead_nxt;
+        t->ahead_nxt = -1;
+    }
+    return PTX_OK;
+}
 
 int ptx_synchronize(ptx_tracer *t) {
     if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
@@ -1724,20 +1853,28 @@ int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba) {
     if (!t || !host_rgba) return set_error(PTX_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(t->device));
     size_t n = (size_t)t->cam.resx * t->cam.resy;
-    uchar4 *d = nullptr;
-    HIPCHECK(hipMalloc(&d, n * 4));
-    int rc = ptx_write_pbo_device(t, iter, d);
+    // the staging buffer stays with the tracer: hipFree would wait for the whole device, i.e. for work traced ahead
+    if (!t->d_pbo) HIPCHECK(hipMalloc(&t->d_pbo, n * 4));
+    int rc = ptx_write_pbo_device(t, iter, t->d_pbo);
     if (rc == PTX_OK) {
-        hipError_t e = hipMemcpyAsync(host_rgba, d, n * 4, hipMemcpyDeviceToHost, t->stream);
+        hipError_t e = hipMemcpyAsync(host_rgba, t->d_pbo, n * 4, hipMemcpyDeviceToHost, t->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
         if (e != hipSuccess) rc = set_error(PTX_ERR_HIP, hipGetErrorString(e));
     }
-    hipFree(d);
     return rc;
 }
 
 double ptx_last_loop_ms(ptx_tracer *t) {
-    if (!t || !t->timing_valid) return 0.0;
+    if (!t) return 0.0;
+    if (t->last_ahead_lane >= 0) {                       // a call served from a batch traced ahead: its share of that batch
+        const ptx_tracer::Ahead &a = t->ahead[t->last_ahead_lane];
+        float ms = 0.f;
+        hipSetDevice(t->device);
+        if (!a.count || hipEventSynchronize(t->ev_ahead1[t->last_ahead_lane]) != hipSuccess) return 0.0;
+        if (hipEventElapsedTime(&ms, t->ev_ahead0[t->last_ahead_lane], t->ev_ahead1[t->last_ahead_lane]) != hipSuccess) return 0.0;
+        return (double)ms / a.count;
+    }
+    if (!t->timing_valid) return 0.0;
     hipSetDevice(t->device);
     float ms = 0.f;
     if (hipEventSynchronize(t->ev_stop) != hipSuccess) return 0.0;
@@ -1755,7 +1892,8 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out) {
     out->bounces = t->traceDepth;
     for (int b = 0; b < 64 && b < t->traceDepth; b++) out->rays_per_bounce[b] = h[b];
     out->rays_total = h[64];
-    out->loop_ms_total = t->loop_ms_total + ptx_last_loop_ms(t);
+    for (int l = 1; l < MAX_LANES; l++) ahead_fold_time(t, l);
+    out->loop_ms_total = t->loop_ms_total + (t->last_ahead_lane >= 0 ? 0.0 : ptx_last_loop_ms(t));
     out->iterations = t->iterations;
     return PTX_OK;
 }
@@ -1850,6 +1988,7 @@ int ptx_set_kernel_timing(ptx_tracer *t, int on) {
     if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
+    ahead_discard(t);
     t->ktiming = on != 0;
     t->kev_used = 0;
     return PTX_OK;

@@ -437,6 +437,58 @@ def test_two_launch_sets_in_flight_identical(gpu_product, scene, opt):
         assert beq(A.read_image(), B.read_image())
 
 
+@pytest.mark.parametrize("scene,opt,res", [("cornellObj.txt", {}, (200, 120)), ("cornell.txt", dict(antialiasing=0), (160, 160)),
+                                           ("cornellSpaceship.txt", dict(depth_of_field=1), (96, 54))])
+def test_render_ahead_is_invisible(gpu_product, scene, opt, res):
+    """ptx_set_render_ahead: one ptx_iterate per call (the reference's pathtrace(iter) loop) served from batches traced in
+    the background gives, after EVERY call, the bits, ray counts and iteration count of the plain call-by-call tracer --
+    across batch boundaries, jumps in the iteration number, a repeated iteration, setting the same camera again (no-op),
+    a real camera change, a bulk render in between, an image reset, and switching the feature off mid-way."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=6)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, **opt) as A, pt.Tracer(s, **opt) as B:
+        B.set_render_ahead(True)
+
+        def both(fn):
+            fn(A); fn(B)
+
+        def same():
+            assert beq(A.read_image(), B.read_image())
+            sa, sb = A.stats(), B.stats()
+            assert sa["rays_total"] == sb["rays_total"] and sa["rays_per_bounce"] == sb["rays_per_bounce"] and sa["iterations"] == sb["iterations"]
+
+        for it in range(1, 71):                                  # two and a bit batches of 32
+            both(lambda T: T.pathtrace(it))
+            if it in (1, 2, 31, 32, 33, 34, 64, 65, 70):
+                same()
+        assert B.stats()["loop_ms_total"] > 0.0 and B.last_loop_ms() > 0.0
+        for it in (200, 201, 202, 202, 203, 150, 151):           # jumps and a repeat
+            both(lambda T: T.pathtrace(it))
+            same()
+        both(lambda T: T.set_camera(s))                          # the same camera again: nothing is dropped, nothing changes
+        both(lambda T: T.pathtrace(152))
+        same()
+        o = s.orbit_init()
+        s.orbit_events(o, [("left", 25, -10), ("right", 15)])    # a real camera change
+        both(lambda T: T.set_camera(s))
+        for it in range(153, 160):
+            both(lambda T: T.pathtrace(it))
+        same()
+        both(lambda T: T.render(160, 9))                         # a bulk call in between
+        both(lambda T: T.pathtrace(169))
+        both(lambda T: T.pathtrace(170))
+        same()
+        both(lambda T: T.reset_image())
+        for it in range(1, 6):
+            both(lambda T: T.pathtrace(it))
+            same()
+        B.set_render_ahead(False)
+        for it in range(6, 10):
+            both(lambda T: T.pathtrace(it))
+        same()
+
+
 def test_strided_render_and_checkpoint_resume(gpu_product, tmp_path):
     """ptx_render_strided traces exactly the iterations it names (each equal to that iteration traced alone), with and
     without batching; a checkpoint written mid-way and resumed in a fresh tracer ends bit-identical to the straight run."""
@@ -498,6 +550,15 @@ def test_headless_driver(gpu_product, tmp_path):
         T.render(1, 3)
         want = T.read_image().reshape(48, 64, 3) / np.float32(3)
     assert np.array_equal(frame, want)
+    # the C++ veneer's own loop -- pathtrace(pbo, frame, iter) once per iteration, as runCuda does -- with and without
+    # render-ahead writes the same frame as the bulk run (40 iterations: past one batch of 32)
+    frames = {}
+    for tag, extra in (("bulk", []), ("percall", ["--per-call"]), ("percall_plain", ["--per-call", "--no-render-ahead"])):
+        o2 = subprocess.check_output([exe, os.path.join(ROOT, "scenes", "cornellObj.txt"), "--res", "64", "48", "--depth", "5",
+                                      "--iterations", "40", "--out", str(tmp_path / tag), "--pfm"] + extra, text=True)
+        assert "time: " in o2 and float(o2.split("time: ")[1].split()[0]) > 0.0
+        frames[tag] = open(glob.glob(str(tmp_path / (tag + ".*.40samp.pfm")))[0], "rb").read()
+    assert frames["bulk"] == frames["percall"] == frames["percall_plain"]
     # --hdr = saveHDR: the mirrored mean frame as RGBE (byte parity of the encoder itself: test_abi.py, CPU)
     hdr = open(glob.glob(str(tmp_path / "img.*.3samp.hdr"))[0], "rb").read()
     head = b"#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y 48 +X 64\n"

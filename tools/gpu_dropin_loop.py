@@ -8,13 +8,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import mygpuraytracer_amd as pt
 s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(1920, 1080), depth=8); s.apply_runcuda_camera()
-N = 60
+N = 120
 vp = C.c_void_p
+AHEAD = os.environ.get("RENDER_AHEAD", "0") == "1"
 with pt.Tracer(s) as T:
     lib, h = T.lib, T.h
+    T.set_render_ahead(AHEAD)
     img = np.zeros((1920 * 1080, 3), np.float32); pbo = np.zeros((1920 * 1080, 4), np.uint8)
     T.render(1, 24); T.synchronize()
-    res = {}
+    res = {"render_ahead": AHEAD}
     t0 = time.perf_counter(); T.render(100, N); T.synchronize(); res["ptx_render_bulk"] = (time.perf_counter() - t0) / N * 1e3
     t0 = time.perf_counter()
     for i in range(N): lib.ptx_iterate(h, 200 + i); lib.ptx_synchronize(h)
