@@ -184,6 +184,7 @@ int ptx_write_image(ptx_tracer *t, const float *host_rgb);  /* the reverse: resu
 int ptx_read_albedo(ptx_tracer *t, float *host_rgb);    /* RenderState.albedo of apps/src (apps_variant only)  */
 /* sendToGPU, apps/src/pathtrace.h:10: a finished (e.g. denoised) host frame -> 8-bit preview, no division by iter */
 int ptx_write_denoised_pbo(ptx_tracer *t, const float *host_rgb, uint8_t *host_rgba);
+int ptx_write_denoised_pbo_device(ptx_tracer *t, const float *host_rgb, void *device_uchar4);   /* pbo in device memory, as the reference's */
 float *ptx_device_image(ptx_tracer *t);                 /* device pointer of the accumulation buffer        */
 int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba);          /* sendImageToPBO, pathtrace.cu:69 */
 int ptx_write_pbo_device(ptx_tracer *t, int iter, void *device_uchar4);

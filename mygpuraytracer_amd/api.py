@@ -157,6 +157,7 @@ def load_library():
     L.ptx_device_image.restype, L.ptx_device_image.argtypes = vp, [vp]
     L.ptx_read_albedo.restype, L.ptx_read_albedo.argtypes = i, [vp, vp]
     L.ptx_write_denoised_pbo.restype, L.ptx_write_denoised_pbo.argtypes = i, [vp, vp, vp]
+    L.ptx_write_denoised_pbo_device.restype, L.ptx_write_denoised_pbo_device.argtypes = i, [vp, vp, vp]
     L.ptx_write_pbo.restype, L.ptx_write_pbo.argtypes = i, [vp, i, vp]
     L.ptx_write_pbo_device.restype, L.ptx_write_pbo_device.argtypes = i, [vp, i, vp]
     L.ptx_last_loop_ms.restype, L.ptx_last_loop_ms.argtypes = C.c_double, [vp]
@@ -437,6 +438,11 @@ class Tracer:
         out = np.zeros((self.width * self.height, 4), np.uint8)
         _check(self.lib.ptx_write_denoised_pbo(self.h, _ptr(rgb), _ptr(out)), "ptx_write_denoised_pbo")
         return out
+
+    def denoised_pbo_device(self, rgb, device_pbo):
+        """sendToGPU (apps/src/pathtrace.cu:673-685): host frame -> 8-bit preview in a device buffer (address as int)"""
+        rgb = np.ascontiguousarray(rgb, np.float32).reshape(self.width * self.height, 3)
+        _check(self.lib.ptx_write_denoised_pbo_device(self.h, _ptr(rgb), device_pbo), "ptx_write_denoised_pbo_device")
 
     def pbo(self, iteration):
         out = np.zeros((self.width * self.height, 4), np.uint8)

@@ -32,6 +32,8 @@ Scene::Scene(const std::string &filename, const std::string &base_dir) : impl_(n
     state.traceDepth = ptx_scene_trace_depth(impl_);
     state.imageName = ptx_scene_image_name(impl_);
     state.image.assign((size_t)state.camera.resolution[0] * state.camera.resolution[1], mi355x::vec3{0.f, 0.f, 0.f});
+    state.albedo = state.image;            // apps/src/scene.cpp:380-383
+    state.output = state.image;
 }
 
 Scene::~Scene() { ptx_scene_free(impl_); }
@@ -74,6 +76,8 @@ void Scene::setResolution(int w, int h) {
     ptx_scene_set_resolution(impl_, w, h);
     state.camera = *ptx_scene_camera(impl_);
     state.image.assign((size_t)w * h, mi355x::vec3{0.f, 0.f, 0.f});
+    state.albedo = state.image;
+    state.output = state.image;
 }
 
 ptx_options &pathtraceOptions() {
@@ -112,8 +116,19 @@ void pathtrace(uchar4 *pbo, int frame, int iter) {
     // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
     check(ptx_set_camera(g_tracer, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
     check(ptx_iterate(g_tracer, iter), "pathtrace");
-    check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");
+    const bool apps = pathtraceOptions().apps_variant != 0;
+    // apps/src builds with AI_DENOISE: no preview from here (sendToGPU shows the denoised frame), the albedo AOV comes back
+    // with the image (apps/src/pathtrace.cu:658-669)
+    if (!apps) check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");
     check(ptx_read_image(g_tracer, &hst_scene->state.image[0].x), "image readback");     // :555-556
+    if (apps) check(ptx_read_albedo(g_tracer, &hst_scene->state.albedo[0].x), "albedo readback");
+}
+
+// apps/src/pathtrace.cu:673-685: the denoised frame in state.output -> the pbo, scaled by 255 and clamped, no division by iter
+void sendToGPU(uchar4 *pbo, int iter) {
+    (void)iter;                  // passed to the kernel but unused there as well (apps/src/pathtrace.cu:96-116)
+    if (!g_tracer || !hst_scene) { fprintf(stderr, "sendToGPU called before pathtraceInit\n"); exit(EXIT_FAILURE); }
+    check(ptx_write_denoised_pbo_device(g_tracer, &hst_scene->state.output[0].x, pbo), "sendToGPU");
 }
 
 ptx_tracer *pathtraceHandle() { return g_tracer; }

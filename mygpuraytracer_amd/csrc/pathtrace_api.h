@@ -31,6 +31,8 @@ struct RenderState {
     unsigned int iterations;
     int traceDepth;
     std::vector<mi355x::vec3> image;      // sum of per-iteration radiance, row-major x + y*W, y = 0 on top
+    std::vector<mi355x::vec3> albedo;     // apps/src/sceneStructs.h:100: first-hit albedo of iteration 1 (apps_variant only)
+    std::vector<mi355x::vec3> output;     // apps/src/sceneStructs.h:101: the denoiser's result, input of sendToGPU
     std::string imageName;
 };
 
@@ -71,4 +73,5 @@ PerformanceTimer &timer();                              // src/pathtrace.h:6
 void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7
 void pathtraceFree();                                   // src/pathtrace.h:8
 void pathtrace(uchar4 *pbo, int frame, int iteration);  // src/pathtrace.h:9 ; pbo may be NULL (no preview)
+void sendToGPU(uchar4 *pbo, int iter);                  // apps/src/pathtrace.h:10 : state.output -> 8-bit preview in the device pbo
 ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state

@@ -1009,6 +1009,7 @@ struct ptx_tracer {
     hipEvent_t ev_ahead0[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_ahead1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     int uses_uv = 0;
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
+    float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
     unsigned long long *d_stamps = nullptr;              // diagnostic build only
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
@@ -1109,7 +1110,7 @@ int free_tracer(ptx_tracer *t) {
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
-    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps); hipFree(t->d_pbo);
+    hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps); hipFree(t->d_pbo); hipFree(t->d_denoised);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
     if (t->ev_start) hipEventDestroy(t->ev_start);
     if (t->ev_stop) hipEventDestroy(t->ev_stop);
@@ -1832,6 +1833,21 @@ int ptx_write_denoised_pbo(ptx_tracer *t, const float *host_rgb, uint8_t *host_r
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     hipFree(d_in); hipFree(d_out);
     if (e != hipSuccess) return set_error(PTX_ERR_HIP, hipGetErrorString(e));
+    return PTX_OK;
+}
+
+// sendToGPU itself (apps/src/pathtrace.cu:673-685): host frame in, the preview written to a DEVICE pbo, as the reference's
+// mapped GL buffer is
+int ptx_write_denoised_pbo_device(ptx_tracer *t, const float *host_rgb, void *device_uchar4) {
+    if (!t || !host_rgb) return set_error(PTX_ERR_INVALID, "null argument");
+    if (!device_uchar4) return PTX_OK;                    // NULL pbo => skip, like ptx_write_pbo_device
+    HIPCHECK(hipSetDevice(t->device));
+    const size_t n = (size_t)t->cam.resx * t->cam.resy;
+    if (!t->d_denoised) HIPCHECK(hipMalloc(&t->d_denoised, sizeof(float) * 3 * n));      // dev_denoised_output, kept like the reference's
+    HIPCHECK(hipMemcpyAsync(t->d_denoised, host_rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice, t->stream));
+    hipLaunchKernelGGL(k_pbo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t->stream, (uchar4 *)device_uchar4, (int)n, 1, t->d_denoised);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(t->stream));            // host_rgb may be reused by the caller right away
     return PTX_OK;
 }
 

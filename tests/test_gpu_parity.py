@@ -615,6 +615,12 @@ def test_apps_variant_on_device(gpu_product, O, tag, scene, res, batch):
     pbo = T.denoised_pbo(frame)
     want = np.clip((frame.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
     assert np.array_equal(pbo[:, :3], want) and not pbo[:, 3].any()
+    # sendToGPU's own shape: the pbo is device memory (apps/src/pathtrace.cu:673-685); same bytes
+    import torch
+    dpbo = torch.full((len(frame), 4), 7, dtype=torch.uint8, device="cuda:0")
+    T.denoised_pbo_device(frame, dpbo.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dpbo.cpu().numpy(), pbo)
     T.close()
     O.set_apps_variant(0)
 
