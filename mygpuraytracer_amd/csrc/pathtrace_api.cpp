@@ -110,7 +110,7 @@ void pathtraceFree() {          // safe before init and idempotent, as main.cpp:
     g_tracer = nullptr;
 }
 
-void pathtrace(uchar4 *pbo, int frame, int iter) {
+void pathtrace(void *pbo, int frame, int iter) {
     (void)frame;                 // unused by the reference as well
     if (!g_tracer || !hst_scene) { fprintf(stderr, "pathtrace called before pathtraceInit\n"); exit(EXIT_FAILURE); }
     // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
@@ -125,7 +125,7 @@ void pathtrace(uchar4 *pbo, int frame, int iter) {
 }
 
 // apps/src/pathtrace.cu:673-685: the denoised frame in state.output -> the pbo, scaled by 255 and clamped, no division by iter
-void sendToGPU(uchar4 *pbo, int iter) {
+void sendToGPU(void *pbo, int iter) {
     (void)iter;                  // passed to the kernel but unused there as well (apps/src/pathtrace.cu:96-116)
     if (!g_tracer || !hst_scene) { fprintf(stderr, "sendToGPU called before pathtraceInit\n"); exit(EXIT_FAILURE); }
     check(ptx_write_denoised_pbo_device(g_tracer, &hst_scene->state.output[0].x, pbo), "sendToGPU");

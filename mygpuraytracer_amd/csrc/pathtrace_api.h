@@ -15,7 +15,10 @@
 
 #include "../../include/mi355x_pathtracer.h"
 
-struct uchar4;          // HIP's vector type; the pbo argument is a device pointer exactly as in the reference
+// The pbo arguments are device pointers to uchar4 exactly as in the reference (the mapped GL buffer of src/main.cpp:131-135).
+// They are declared void* so that this header compiles -- and the calls link -- whether or not the caller's translation unit
+// has HIP's vector types (hip_runtime.h makes uchar4 a typedef of a class template, which can neither be forward-declared
+// nor be mangled the same way from a file without it); `pathtrace(pbo_dptr, frame, iteration)` converts implicitly.
 
 namespace mi355x {
 struct vec3 { float x, y, z; };
@@ -72,6 +75,6 @@ bool &pathtraceRenderAhead();                           // true (default): patht
 PerformanceTimer &timer();                              // src/pathtrace.h:6
 void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7
 void pathtraceFree();                                   // src/pathtrace.h:8
-void pathtrace(uchar4 *pbo, int frame, int iteration);  // src/pathtrace.h:9 ; pbo may be NULL (no preview)
-void sendToGPU(uchar4 *pbo, int iter);                  // apps/src/pathtrace.h:10 : state.output -> 8-bit preview in the device pbo
+void pathtrace(void *pbo, int frame, int iteration);    // src/pathtrace.h:9 (uchar4 *pbo); pbo may be NULL (no preview)
+void sendToGPU(void *pbo, int iter);                    // apps/src/pathtrace.h:10 (uchar4 *pbo): state.output -> 8-bit preview in the device pbo
 ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state

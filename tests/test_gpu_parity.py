@@ -625,6 +625,40 @@ def test_apps_variant_on_device(gpu_product, O, tag, scene, res, batch):
     O.set_apps_variant(0)
 
 
+@pytest.mark.parametrize("apps", [False, True])
+def test_cpp_veneer_like_main_cpp(gpu_product, tmp_path, apps):
+    """tests/veneer_check.cpp: the C++ veneer with the reference's names driven the way src/main.cpp (and apps/src/main.cpp)
+    drive pathtrace.h -- Free before Init, one pathtrace(device pbo, frame, iter) per iteration (render-ahead on, 40 > one
+    batch), timer(), Free twice -- leaves in state.image / the pbo / state.albedo / sendToGPU's pbo exactly what the C ABI
+    gives when driven from here."""
+    import subprocess
+    pt = gpu_product
+    exe = tmp_path / "veneer_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "veneer_check.cpp"),
+                           "-L" + os.path.join(ROOT, "mygpuraytracer_amd"), "-lmi355x_pathtracer", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mygpuraytracer_amd") + ",-rpath,/opt/rocm/lib"])
+    W, H, D, N = 64, 48, 5, 40
+    scene = os.path.join(ROOT, "scenes", "cornellObj.txt")
+    out = subprocess.check_output([str(exe), scene, str(W), str(H), str(D), str(N), str(tmp_path / "v")] + (["apps"] if apps else []), text=True)
+    assert float(out.split("time: ")[1].split()[0]) > 0.0
+    rd = lambda ext, dt: np.frombuffer(open(str(tmp_path / "v") + ext, "rb").read(), dt)
+    s = pt.Scene(scene, res=(W, H), depth=D)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, apps_variant=1 if apps else 0) as T:
+        T.render(1, N)
+        img = T.read_image()
+        assert np.array_equal(rd(".image", np.float32).reshape(-1, 3), img)
+        if not apps:
+            assert np.array_equal(rd(".pbo", np.uint8).reshape(-1, 4), T.pbo(N))
+        else:
+            assert (rd(".pbo", np.uint8) == 0x5a).all()                      # AI_DENOISE: pathtrace leaves the pbo alone
+            assert np.array_equal(rd(".albedo", np.float32).reshape(-1, 3), T.read_albedo())
+            fake = np.stack([img[:, 0] / np.float32(N) * np.float32(1.5) - np.float32(0.1), img[:, 1] / np.float32(N),
+                             img[:, 2] / np.float32(N) * np.float32(3.0)], 1).astype(np.float32)
+            assert np.array_equal(rd(".pbo2", np.uint8).reshape(-1, 4), T.denoised_pbo(fake))
+
+
 def _scene_from_text(pt, text, tmp_path, res=None, depth=None):
     f = tmp_path / "scene.txt"
     f.write_text(text)

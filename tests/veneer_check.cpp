@@ -1,0 +1,61 @@
+// veneer_check.cpp -- drives the C++ veneer (mygpuraytracer_amd/csrc/pathtrace_api.h) exactly as the reference's main.cpp
+// drives its pathtrace.h: Scene, pathtraceFree/Init, pathtrace(pbo, frame, iter) per iteration with a DEVICE pbo, timer(),
+// and, with `apps`, the apps/src extras (state.albedo, sendToGPU).  Writes what it saw to OUT.{image,albedo,pbo,pbo2} for
+// tests/test_gpu_parity.py to compare with the C ABI driven from Python.  Built by the test with g++.
+//   veneer_check SCENE W H DEPTH ITERS OUT [apps]
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../mygpuraytracer_amd/csrc/pathtrace_api.h"
+
+static void dump(const std::string &path, const void *p, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f || fwrite(p, 1, n, f) != n) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
+    fclose(f);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 7) return 2;
+    const int w = atoi(argv[2]), h = atoi(argv[3]), depth = atoi(argv[4]), iters = atoi(argv[5]);
+    const std::string out = argv[6];
+    const bool apps = argc > 7 && std::string(argv[7]) == "apps";
+    Scene *scene = new Scene(argv[1]);
+    scene->setResolution(w, h);
+    scene->state.traceDepth = depth;
+    scene->applyRunCudaCamera();
+    pathtraceOptions().apps_variant = apps ? 1 : 0;
+    pathtraceFree();                                   // main.cpp:129: Free before the first Init must be harmless
+    pathtraceInit(scene);
+    const size_t n = (size_t)w * h;
+    uchar4 *pbo = nullptr;                             // HIP's own uchar4, as in a maintainer's main.cpp
+    if (hipMalloc((void **)&pbo, n * 4) != hipSuccess || hipMemset(pbo, 0x5a, n * 4) != hipSuccess) { fprintf(stderr, "no device pbo\n"); return 1; }
+    float sum = 0.f;
+    for (int it = 1; it <= iters; it++) {
+        pathtrace(pbo, 0, it);
+        sum += timer().getGpuElapsedTimeForPreviousOperation();
+    }
+    std::vector<unsigned char> host(n * 4);
+    if (hipMemcpy(host.data(), pbo, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    dump(out + ".image", scene->state.image.data(), n * 12);
+    dump(out + ".pbo", host.data(), n * 4);            // apps: untouched (AI_DENOISE skips sendImageToPBO), else the preview of `iters`
+    if (apps) {
+        dump(out + ".albedo", scene->state.albedo.data(), n * 12);
+        for (size_t i = 0; i < n; i++) {               // stand-in for the denoiser: mean radiance, partly out of range on purpose
+            scene->state.output[i].x = scene->state.image[i].x / iters * 1.5f - 0.1f;
+            scene->state.output[i].y = scene->state.image[i].y / iters;
+            scene->state.output[i].z = scene->state.image[i].z / iters * 3.0f;
+        }
+        sendToGPU(pbo, iters);
+        if (hipMemcpy(host.data(), pbo, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        dump(out + ".pbo2", host.data(), n * 4);
+    }
+    printf("time: %g\n", sum);
+    (void)hipFree(pbo);
+    pathtraceFree();
+    pathtraceFree();                                   // idempotent
+    delete scene;
+    return sum > 0.f ? 0 : 3;
+}
