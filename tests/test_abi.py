@@ -127,6 +127,18 @@ def test_hdr_writer_matches_savehdr_bytes(tmp_path):
             assert got == lp.read_bytes(), name
 
 
+def test_stream_compaction_namespaces_cpu(product, tmp_path):
+    """csrc/stream_compaction_api.h: StreamCompaction::CPU::{scan, compactWithoutScan, compactWithScan}, timer() and
+    ilog2 / ilog2ceil spelled as the reference's users spell them (stream_compaction/cpu.h, common.h) compile with g++ and
+    give the right answers without a GPU (tests/sc_veneer_check.cpp; the GPU namespaces run in the GPU tier)."""
+    import subprocess
+    exe = tmp_path / "sc_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", str(exe), os.path.join(ROOT, "tests", "sc_veneer_check.cpp"),
+                           "-L" + os.path.dirname(product.LIB_PATH), "-lmi355x_pathtracer", "-Wl,-rpath," + os.path.dirname(product.LIB_PATH)])
+    out = subprocess.check_output([str(exe), "cpu"], text=True)
+    assert "cpu: 0 mismatches" in out
+
+
 def test_headers_are_plain_c_and_link(product, tmp_path):
     """The boundary is a C ABI: both headers compile as C99 (-pedantic) and a C program links against the library and
     calls entry points that need no GPU (what a cgo / JNI / ctypes binding would do)."""

@@ -109,3 +109,18 @@ def test_device_forms_degenerate(gpu_product):
     sc.compact_device(1 << 22, out.data_ptr(), ones.data_ptr(), count.data_ptr(), big_ws.data_ptr())
     torch.cuda.synchronize()
     assert int(count.item()) == 1 << 22 and bool((out == 1).all())
+
+
+def test_reference_namespaces_through_the_cpp_veneer(gpu_product, tmp_path):
+    """tests/sc_veneer_check.cpp: StreamCompaction::{Naive,Efficient,Thrust}::scan and Efficient::compact with the
+    reference's spelling and host pointers (csrc/stream_compaction_api.h) agree with StreamCompaction::CPU on sizes around
+    the tile size; the per-namespace timers report the previous operation."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.join(ROOT, "mygpuraytracer_amd")
+    exe = tmp_path / "sc_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", str(exe), os.path.join(ROOT, "tests", "sc_veneer_check.cpp"),
+                           "-L" + lib_dir, "-lmi355x_pathtracer", "-Wl,-rpath," + lib_dir])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert "all: 0 mismatches" in out
