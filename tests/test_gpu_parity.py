@@ -279,8 +279,9 @@ def test_full_size_c1_c2_c3_against_the_reference(gpu_product, tag, scene, res, 
 
 
 def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product):
-    """BASELINE config 5 at full size (3840x2160, depth 8, AA + DoF, textured 20448-triangle stand-in): far too slow for
-    the CPU oracle, so the size-independent property is checked instead -- the fast path (BVH, mesh search as a kernel of
+    """BASELINE config 5 at full size (3840x2160, depth 8, AA + DoF, textured 20448-triangle stand-in): minutes for
+    the CPU oracle (it runs at 1920x1080 in test_c5_with_the_20k_triangle_mesh_against_oracle, and at full size with the
+    320-triangle mesh in test_full_size_c5_against_oracle), so here the size-independent property is checked -- the fast path (BVH, mesh search as a kernel of
     its own, two launch sets in flight) and the reference-shaped path (loop over all faces inside the bounce kernel, one
     iteration at a time) give the same image bits and ray counts.  Small frames of the same scene are checked against
     the oracle in test_sorted_stream_parity / test_stage_parity."""
@@ -317,6 +318,39 @@ def test_full_size_c4_against_oracle(gpu_product, O):
     """One whole 1920x1080 iteration against the CPU oracle (about 4 s of CPU): identical image."""
     s, T = make_pair(gpu_product, O, "cornellObj.txt", (1920, 1080), 8)
     O.iterate(1); T.pathtrace(1)
+    assert beq(T.read_image(), O.image())
+    assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
+    T.close()
+
+
+def test_full_size_c5_against_oracle(gpu_product, O):
+    """BASELINE config 5 at full size -- 3840x2160, depth 8, AA + DoF, the textured stand-in mesh (320 triangles, BVH and
+    split mesh search on the GPU) -- one whole iteration against the CPU oracle, which loops over all faces for every ray
+    like the reference (its per-path loops on 16 threads: same bits, tests/test_oracle_golden.py; about 10 s): identical
+    image and rays per bounce, 21.9 M ray-bounces."""
+    s, T = make_pair(gpu_product, O, "cornellSpaceship.txt", (3840, 2160), 8, depth_of_field=1)
+    O.set_threads(16)
+    try:
+        O.iterate(1)
+    finally:
+        O.set_threads(1)
+    T.pathtrace(1)
+    assert beq(T.read_image(), O.image())
+    assert T.stats()["rays_per_bounce"] == O.live_counts().tolist() and sum(O.live_counts().tolist()) > 21_000_000
+    T.close()
+
+
+def test_c5_with_the_20k_triangle_mesh_against_oracle(gpu_product, O):
+    """Config 5's scene with the 20 448-triangle stand-in at 1920x1080 (the oracle's loop over all faces for every ray sets
+    the size: 5.5 M ray-bounces x 20 448 triangles, 16 threads, about 20 s): the BVH + split mesh search on the GPU give the image
+    and the ray counts of the reference's brute-force loop, bit for bit."""
+    s, T = make_pair(gpu_product, O, "cornellSpaceship20k.txt", (1920, 1080), 8, depth_of_field=1)
+    O.set_threads(16)
+    try:
+        O.iterate(1)
+    finally:
+        O.set_threads(1)
+    T.pathtrace(1)
     assert beq(T.read_image(), O.image())
     assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
     T.close()
