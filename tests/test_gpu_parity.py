@@ -314,24 +314,26 @@ def test_tuning_knobs_do_not_change_results(gpu_product, O, monkeypatch):
         monkeypatch.delenv(var)
 
 
-@pytest.mark.parametrize("scene,res,depth,opt", [("cornellObj.txt", (1920, 1080), 8, {}),                       # C4
-                                                 ("cornellGlass.txt", (1920, 1080), 12, {}),                    # C3
-                                                 ("cornell.txt", (800, 800), 8, dict(antialiasing=0)),          # C2 (cache)
-                                                 ("sphere.txt", (256, 256), 4, {})])                            # C1
-def test_full_size_frames_against_oracle(gpu_product, O, scene, res, depth, opt):
+@pytest.mark.parametrize("scene,res,depth,opt,iters", [("cornellObj.txt", (1920, 1080), 8, {}, 2),                    # C4
+                                                       ("cornellGlass.txt", (1920, 1080), 12, {}, 2),                 # C3
+                                                       ("cornell.txt", (800, 800), 8, dict(antialiasing=0), 64),      # C2: 64 spp, cache
+                                                       ("sphere.txt", (256, 256), 4, {}, 2)])                         # C1
+def test_full_size_frames_against_oracle(gpu_product, O, scene, res, depth, opt, iters):
     """Whole frames of BASELINE configs 1-4 at their full sizes against the CPU oracle (its per-path loops on 16 threads,
-    a few seconds): two iterations, identical image and rays per bounce."""
+    a few seconds each): identical accumulated image and rays per bounce -- after two iterations, and for config 2 after the
+    64 spp its name gives (one bulk call: 64 iterations in batches from the first-bounce cache)."""
     s, T = make_pair(gpu_product, O, scene, res, depth, **opt)
     O.set_threads(16)
     try:
-        O.iterate(1); O.iterate(2)
+        for it in range(1, iters + 1):
+            O.iterate(it)
     finally:
         O.set_threads(1)
-    T.pathtrace(1); T.pathtrace(2)
+    T.render(1, iters)
     assert beq(T.read_image(), O.image())
-    want = O.live_counts().tolist()                      # of iteration 2; the oracle stops at the first empty bounce
+    want = O.live_counts().tolist()                      # of the last iteration; the oracle stops at the first empty bounce
     got = T.stats()["rays_per_bounce"]
-    if opt.get("antialiasing", 1) == 0:                  # first-bounce cache: iteration 2 starts from the cached bounce-0 stream
+    if opt.get("antialiasing", 1) == 0:                  # first-bounce cache: later iterations start from the cached bounce-0 stream
         assert got[0] == 0
         got[0] = want[0]
     assert got[:len(want)] == want and not any(got[len(want):])
