@@ -373,6 +373,31 @@ def test_c5_with_the_20k_triangle_mesh_against_oracle(gpu_product, O):
     T.close()
 
 
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_full_size_tile_of_an_8_way_split_against_oracle(gpu_product, O, rank):
+    """What one rank of the 8-GPU run of BASELINE config 4 computes -- its interleaved 8-row blocks of the 1920x1080 frame,
+    as a stream of its own, 40 iterations in the batching a rank uses -- against the oracle restricted to the same rows:
+    identical partial frame (foreign rows zero) and ray counts."""
+    from mygpuraytracer_amd import multigpu
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", (1920, 1080), 8, tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=8)
+    O.set_tile(multigpu.TILE_ROWS, rank, 8); O.pt_init()
+    try:
+        assert T.owned_pixels() == O.pixelcount()
+        O.set_threads(16)
+        for it in range(1, 41):
+            O.iterate(it)
+        T.render(1, 40)
+        img = T.read_image()
+        assert beq(img, O.image())
+        assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
+        mine = np.repeat((np.arange(1080) // multigpu.TILE_ROWS) % 8 == rank, 1920)
+        assert not img[~mine].any() and img[mine].any()
+    finally:
+        O.set_threads(1)
+        O.set_tile(0, 0, 1)
+        T.close()
+
+
 def test_tile_split_matches_oracle_on_the_same_tile(gpu_product, O):
     """Multi-GPU row tiles: each tile is its own stream (local stream indices), so a tile must equal the oracle run
     on that tile; the tiles together cover every pixel exactly once."""
