@@ -193,6 +193,10 @@ def main():
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
                     help="N > 1: 'tiles' = interleaved pixel-row blocks per rank (what north_star prescribes, the default); "
                     "'iterations' = every rank traces the full frame for every N-th iteration (sums to the single-GPU frame)")
+    ap.add_argument("--exchange", default="reduce", choices=["reduce", "gather"],
+                    help="N > 1, tiles: how rank 0 gets the frame: 'reduce' = one RCCL reduce(SUM) of the full accumulation buffer "
+                    "(what north_star prescribes, the default); 'gather' = every rank sends only the rows it owns "
+                    "(multigpu.assemble_tiles: 1/N of the bytes per rank, same frame bit for bit)")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="launch sets in flight (ptx_options.lanes): 0 = library default (3: k_move of one batch of iterations "
                     "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
@@ -223,8 +227,11 @@ def main():
     torch.cuda.set_device(device)
 
     def reduce_frame(img):
-        """One reduce(SUM) of the accumulation buffer to rank 0: RCCL on the device buffer, or (gloo rehearsal) via host."""
-        if args.backend == "nccl":
+        """One reduce(SUM) of the accumulation buffer to rank 0: RCCL on the device buffer, or (gloo rehearsal) via host.
+        --exchange gather: the owned rows only (pixel tiles; iteration sharding needs the sum)."""
+        if args.exchange == "gather" and not (world > 1 and args.shard == "iterations"):
+            multigpu.assemble_tiles(img, RES[0], RES[1], multigpu.TILE_ROWS, dst=0, via_host=args.backend != "nccl")
+        elif args.backend == "nccl":
             dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
         else:
             h = img.cpu()
@@ -323,7 +330,7 @@ def main():
                config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb,
                            parallelism=("1 GPU" if world == 1 else
                                         "%d ranks taking turns over the iterations of the full frame + 1 RCCL reduce/run" % world if by_iter else
-                                        "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL reduce/run" % (world, multigpu.TILE_ROWS))),
+                                        "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL %s/run" % (world, multigpu.TILE_ROWS, args.exchange))),
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)

@@ -25,6 +25,31 @@ def owned_rows(height, tile_rows, rank, world):
     return [y for y in range(height) if (y // tile_rows) % world == rank]
 
 
+def assemble_tiles(image, width, height, tile_rows=TILE_ROWS, dst=0, via_host=False):
+    """The alternative to the reduce for pixel-row tiles ("gather of disjoint ranges, 7/8 of the bytes, no
+    adds"): every rank packs the rows it owns into one contiguous buffer, ``gather`` (RCCL: point-to-point sends over xGMI,
+    all seven links into `dst` at once) brings the world's packs to `dst`, which copies each into its rows.  1/world of the
+    reduce's bytes per rank.  The frame on `dst` is bit-identical to what reduce(SUM) gives, since foreign rows hold zeros
+    there.  `image` is the flat W*H*3 accumulation buffer; ranks other than `dst` keep theirs unchanged.  via_host: stage
+    through host memory (gloo rehearsal of a GPU run)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    frame = image.view(height, width * 3)
+    rows = [torch.tensor(owned_rows(height, tile_rows, r, world), dtype=torch.long) for r in range(world)]
+    most = max(len(r) for r in rows)                      # the last ranks may own one block less: pad the pack
+    comm_dev = torch.device("cpu") if via_host else image.device
+    pack = torch.zeros(most, width * 3, dtype=image.dtype, device=comm_dev)
+    mine = rows[rank].to(image.device)
+    if len(mine):
+        pack[:len(mine)] = frame.index_select(0, mine).to(comm_dev)
+    packs = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
+    dist.gather(pack, packs, dst=dst)
+    if rank == dst:
+        for r in range(world):
+            if r != dst and len(rows[r]):
+                frame.index_copy_(0, rows[r].to(image.device), packs[r][:len(rows[r])].to(image.device))
+    return image if rank == dst else None
+
+
 def render_distributed(renderer, width, height, iter_first, count, device, reduce_to=0):
     """Runs `count` iterations of this rank's tile and reduces the accumulation buffers.
 

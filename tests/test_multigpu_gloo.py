@@ -169,3 +169,45 @@ def test_iteration_share_rule():
             f, n = multigpu.iteration_share(first, count, r, world)
             seen += [f + k * world for k in range(n)]
         assert sorted(seen) == list(range(first, first + count))
+
+
+# ---- the gather of owned rows as the exchange (instead of the reduce) ------------------------------------------------
+def _worker_gather(rank, world, port, q, W, H, rows):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mygpuraytracer_amd import multigpu
+    rng = np.random.default_rng(100 + rank)
+    img = np.zeros((H, W * 3), np.float32)
+    own = multigpu.owned_rows(H, rows, rank, world)
+    img[own] = rng.random((len(own), W * 3), dtype=np.float32) + np.float32(rank)
+    a, b = torch.from_numpy(img.reshape(-1).copy()), torch.from_numpy(img.reshape(-1).copy())
+    gathered = multigpu.assemble_tiles(a, W, H, rows, dst=0)
+    dist.reduce(b, dst=0, op=dist.ReduceOp.SUM)
+    q.put((rank, None if gathered is None else gathered.numpy().copy(), b.numpy().copy() if rank == 0 else None, img.reshape(-1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,rows", [(3, 16, 41, 4), (2, 8, 7, 8)])
+def test_gather_of_owned_rows_equals_the_reduce(world, W, H, rows):
+    """multigpu.assemble_tiles: ranks own different numbers of rows (41 rows in blocks of 4 over 3 ranks; a rank that owns
+    nothing: 7 rows in one block of 8 over 2 ranks) -- the packs are padded, the frame assembled on rank 0 equals what
+    reduce(SUM) of the full buffers gives, bit for bit, and the other ranks keep their buffers."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, q, W, H, rows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, gathered, reduced, own = q.get(timeout=180)
+        got[rank] = (gathered, reduced, own)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got[r][0] is None for r in range(1, world))
+    want = sum(got[r][2] for r in range(world))
+    assert np.array_equal(got[0][0], got[0][1]) and np.array_equal(got[0][0], want)
