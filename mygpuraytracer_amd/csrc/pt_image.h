@@ -1,9 +1,12 @@
-// pt_image.h -- image output with the semantics of the reference's saveImage + image::savePNG
-// (src/main.cpp:81-102, src/image.cpp:22-39), without stb_image_write: a self-contained PNG encoder (zlib stream
-// of stored blocks -- valid PNG, no compression) and a PFM writer for the raw fp32 frame.
+// pt_image.h -- image output with the semantics of the reference's saveImage + image::savePNG / saveHDR
+// (src/main.cpp:81-102, src/image.cpp:22-45) without stb_image_write: own PNG and Radiance encoders that take the same
+// decisions as the writer the reference vendors (external/include/stb_image_write.h v0.98), so the files are the same
+// bytes (tests/golden/png_files.npz, hdr_files.npz were written by that code), plus a PFM writer for the raw fp32 frame
+// and the checkpoint format.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <string>
 #include <cstring>
@@ -33,22 +36,127 @@ inline void chunk(std::vector<uint8_t> &png, const char type[4], const std::vect
     put32(png, crc32(td.data(), td.size()));
 }
 
-// rgb8: h rows of w*3 bytes, top row first
-inline bool write_png_rgb8(const std::string &path, int w, int h, const uint8_t *rgb8) {
-    std::vector<uint8_t> raw;
-    raw.reserve((size_t)h * (w * 3 + 1));
-    for (int y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), rgb8 + (size_t)y * w * 3, rgb8 + (size_t)(y + 1) * w * 3); }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
-    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
-        size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
-        z.push_back(off + n >= raw.size() ? 1 : 0);
-        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
-        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
-        if (raw.empty()) break;
+// ---- PNG as stbi_write_png writes it (stb_image_write.h:448-711) ------------------------------------------------------
+// zlib stream: one fixed-Huffman block; matches are found through a hash of the next three bytes into 16384 buckets, each
+// keeping its last 8..16 positions (at 16 the older 8 are dropped); the longest match wins, the later position on ties;
+// a match is given up for a literal when the next byte starts a longer one; positions inside a match are not entered.
+inline void zlib_like_stb(const std::vector<uint8_t> &in, std::vector<uint8_t> &out) {
+    static const uint16_t len_base[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 259};
+    static const uint8_t len_extra[] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dist_base[] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 32768};
+    static const uint8_t dist_extra[] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    constexpr int BUCKETS = 16384, KEEP = 8;
+    const long long n = (long long)in.size();
+    const uint8_t *d = in.data();
+    uint32_t bitbuf = 0;
+    int bitcount = 0;
+    auto add = [&](uint32_t code, int bits) {                       // LSB first
+        bitbuf |= code << bitcount;
+        bitcount += bits;
+        while (bitcount >= 8) { out.push_back((uint8_t)bitbuf); bitbuf >>= 8; bitcount -= 8; }
+    };
+    auto rev = [](int code, int bits) { int r = 0; while (bits--) { r = (r << 1) | (code & 1); code >>= 1; } return (uint32_t)r; };
+    auto sym = [&](int v) {                                         // the fixed literal/length code of RFC 1951 3.2.6
+        if (v <= 143) add(rev(0x30 + v, 8), 8);
+        else if (v <= 255) add(rev(0x190 + v - 144, 9), 9);
+        else if (v <= 279) add(rev(v - 256, 7), 7);
+        else add(rev(0xc0 + v - 280, 8), 8);
+    };
+    auto hash3 = [&](long long i) {
+        uint32_t h = d[i] + ((uint32_t)d[i + 1] << 8) + ((uint32_t)d[i + 2] << 16);
+        h ^= h << 3; h += h >> 5; h ^= h << 4; h += h >> 17; h ^= h << 25; h += h >> 6;
+        return (int)(h & (BUCKETS - 1));
+    };
+    auto run = [&](long long a, long long b, long long limit) {     // common prefix, at most 258
+        long long k = 0;
+        while (k < limit && k < 258 && d[a + k] == d[b + k]) k++;
+        return (int)k;
+    };
+    out.push_back(0x78); out.push_back(0x5e);
+    add(1, 1); add(1, 2);                                           // last block, fixed Huffman
+    std::vector<std::vector<long long>> table(BUCKETS);
+    long long i = 0;
+    while (i < n - 3) {
+        std::vector<long long> &bucket = table[hash3(i)];
+        int best = 3;
+        long long where = -1;
+        for (long long pos : bucket)
+            if (pos > i - 32768) {
+                const int m = run(pos, i, n - i);
+                if (m >= best) { best = m; where = pos; }
+            }
+        if ((int)bucket.size() == 2 * KEEP) bucket.erase(bucket.begin(), bucket.begin() + KEEP);
+        bucket.push_back(i);
+        if (where >= 0) {
+            for (long long pos : table[hash3(i + 1)])
+                if (pos > i - 32767 && run(pos, i + 1, n - i - 1) > best) { where = -1; break; }
+        }
+        if (where >= 0) {
+            const int dist = (int)(i - where);
+            int j = 0;
+            while (best > len_base[j + 1] - 1) j++;
+            sym(j + 257);
+            if (len_extra[j]) add((uint32_t)(best - len_base[j]), len_extra[j]);
+            j = 0;
+            while (dist > dist_base[j + 1] - 1) j++;
+            add(rev(j, 5), 5);
+            if (dist_extra[j]) add((uint32_t)(dist - dist_base[j]), dist_extra[j]);
+            i += best;
+        } else {
+            sym(d[i]);
+            i++;
+        }
     }
-    put32(z, (b << 16) | a);
+    for (; i < n; i++) sym(d[i]);
+    sym(256);
+    while (bitcount) add(0, 1);
+    uint32_t s1 = 1, s2 = 0;                                        // Adler-32
+    for (long long k = 0; k < n; k++) { s1 = (s1 + d[k]) % 65521; s2 = (s2 + s1) % 65521; }
+    out.push_back((uint8_t)(s2 >> 8)); out.push_back((uint8_t)s2); out.push_back((uint8_t)(s1 >> 8)); out.push_back((uint8_t)s1);
+}
+
+inline int paeth_pick(int a, int b, int c) {
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+// rgb8: h rows of w*3 bytes, top row first.  Per row the filter with the smallest sum of |signed byte| is chosen, the first
+// such in the order none, sub, up, average, Paeth; the first row has no row above it, so its "up" is "none" and its
+// average and Paeth use only the pixel to the left -- but are still labelled 2, 3, 4.
+inline bool write_png_rgb8(const std::string &path, int w, int h, const uint8_t *rgb8) {
+    const int n = 3, rowb = w * n;
+    std::vector<uint8_t> raw((size_t)h * (rowb + 1));
+    std::vector<int8_t> line((size_t)rowb);
+    for (int y = 0; y < h; y++) {
+        const uint8_t *z = rgb8 + (size_t)y * rowb, *up = z - rowb;
+        auto filter_row = [&](int k) {
+            for (int i = 0; i < rowb; i++) {
+                const int left = i >= n ? z[i - n] : 0, above = y ? up[i] : 0, diag = (y && i >= n) ? up[i - n] : 0;
+                int v;
+                switch (k) {
+                    case 0: v = z[i]; break;
+                    case 1: v = z[i] - left; break;
+                    case 2: v = z[i] - above; break;
+                    case 3: v = z[i] - ((left + above) >> 1); break;
+                    default: v = z[i] - paeth_pick(left, above, diag); break;
+                }
+                line[i] = (int8_t)v;
+            }
+        };
+        int best = 0, bestval = 0x7fffffff;
+        for (int k = 0; k < 5; k++) {
+            filter_row(k);
+            int est = 0;
+            for (int i = 0; i < rowb; i++) est += abs((int)line[i]);
+            if (est < bestval) { bestval = est; best = k; }
+        }
+        filter_row(best);
+        raw[(size_t)y * (rowb + 1)] = (uint8_t)best;
+        memcpy(&raw[(size_t)y * (rowb + 1) + 1], line.data(), (size_t)rowb);
+    }
+    std::vector<uint8_t> z;
+    zlib_like_stb(raw, z);
     std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     std::vector<uint8_t> ihdr;
     put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);

@@ -212,12 +212,30 @@ def hdr_files(so):
     print("hdr_files.npz:", len(out), "files")
 
 
+def png_files(so):
+    """tests/pngwritecases.py through the stbi_write_png the reference vendors (what image::savePNG calls, src/image.cpp:33)."""
+    import ctypes
+    import tempfile
+    import pngwritecases
+    lib = ctypes.CDLL(so)
+    lib.stbi_write_png.restype = ctypes.c_int
+    lib.stbi_write_png.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        for name, img in pngwritecases.cases().items():
+            path = os.path.join(root, name + ".png")
+            assert lib.stbi_write_png(path.encode(), img.shape[1], img.shape[0], 3, img.ctypes.data, img.shape[1] * 3) == 1
+            out[name] = np.frombuffer(open(path, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "png_files.npz"), **out)
+    print("png_files.npz:", len(out), "files")
+
+
 def main():
     so = build_ref()
     if not so:
         sys.exit("oracle/_ref/libptref.so cannot be built here (no /root/reference)")
-    if sys.argv[1:] == ["hdr"]:                      # only this fixture (the others are unchanged by it)
-        hdr_files(so)
+    if sys.argv[1:] in (["hdr"], ["png"]):           # only this fixture (the others are unchanged by it)
+        (hdr_files if sys.argv[1] == "hdr" else png_files)(so)
         return
     R = RefLib(so)
     rng = np.random.default_rng(20261004)
@@ -370,6 +388,7 @@ def main():
     jpeg_textures(R)
     ngon_faces(R)
     hdr_files(so)
+    png_files(so)
     print("golden fixtures written to", HERE)
 
 

@@ -63,6 +63,42 @@ def test_cpu_stream_compaction_entry_points(product, oracle_lib):
     assert [lib.sc_ilog2ceil(v) for v in (1, 2, 3, 4, 1023, 1025)] == [0, 1, 2, 2, 10, 11]
 
 
+def _png_rgb8_pixels(data, max_rows=None):
+    """Decodes an 8-bit RGB, non-interlaced PNG with zlib + the five row filters -> (w, h, rows as int array [rows, w*3])"""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h = ihdr[:2]
+    assert ihdr[2:] == (8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 3 + 1)
+    nrows = h if max_rows is None else min(h, max_rows)
+    dec = np.zeros((nrows, w * 3), np.int64)
+    for y in range(nrows):
+        f, line = rows[y, 0], rows[y, 1:].astype(np.int64)
+        for i in range(w * 3):
+            a = dec[y, i - 3] if i >= 3 else 0
+            b = dec[y - 1, i] if y else 0
+            c = dec[y - 1, i - 3] if (y and i >= 3) else 0
+            if f == 4:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            else:
+                pred = (0, a, b, (a + b) >> 1)[f]
+            dec[y, i] = (line[i] + pred) & 255
+    return w, h, dec
+
+
 def test_png_writer_matches_saveimage_semantics(tmp_path):
     """pt_image.h: saveImage's x-mirror + savePNG's clamp*255 truncation (src/main.cpp:86-92, src/image.cpp:26-31) and a
     decodable PNG (checked with zlib / PIL-free parsing)."""
@@ -75,24 +111,50 @@ def test_png_writer_matches_saveimage_semantics(tmp_path):
                    ' ptimg::to_rgb8_mirrored(2,2,img,2.f,o); return ptimg::write_png_rgb8("%s/o.png",2,2,o.data())?0:1; }\n' % (ROOT, tmp_path))
     subprocess.check_call(["g++", "-std=c++17", "-o", str(tmp_path / "t"), str(src)])
     subprocess.check_call([str(tmp_path / "t")])
-    data = (tmp_path / "o.png").read_bytes()
-    assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, ihdr = 8, b"", None
-    while pos < len(data):
-        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
-        body = data[pos + 8:pos + 8 + n]
-        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
-        if typ == b"IHDR":
-            ihdr = struct.unpack(">IIBBBBB", body)
-        if typ == b"IDAT":
-            idat += body
-        pos += 12 + n
-    assert ihdr == (2, 2, 8, 2, 0, 0, 0)
-    raw = zlib.decompress(idat)
-    rows = [raw[1:7], raw[8:14]]
+    w, h, rows = _png_rgb8_pixels((tmp_path / "o.png").read_bytes())
+    assert (w, h) == (2, 2)
     # row 0: pixel x=1 (0, .125, clamp(-.5)=0) then x=0 (.25, .5, clamp(1.5)=1)
     assert list(rows[0]) == [0, 31, 0, 63, 127, 255]
     assert list(rows[1]) == [127, 63, 12, 255, 255, 255]
+
+
+def test_png_writer_matches_savepng_bytes(tmp_path):
+    """pt_image.h write_png_rgb8: byte-identical files to image::savePNG's stbi_write_png (src/image.cpp:33) -- the same row
+    filters and the same fixed-Huffman LZ stream as the stb_image_write the reference vendors; tests/golden/png_files.npz
+    was written by that code (make_golden.py png_files).  Also against the live library when oracle/_ref is present, and
+    every file decodes back to its pixels."""
+    import subprocess
+    import sys
+    import zlib
+    sys.path.insert(0, os.path.dirname(__file__))
+    import pngwritecases
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "%s/mygpuraytracer_amd/csrc/pt_image.h"\n'
+                   'int main(int argc, char **argv){ int w = atoi(argv[1]), h = atoi(argv[2]); std::vector<uint8_t> px((size_t)w*h*3);\n'
+                   ' FILE *f = fopen(argv[3], "rb"); if (!f || fread(px.data(), 1, px.size(), f) != px.size()) return 2; fclose(f);\n'
+                   ' return ptimg::write_png_rgb8(argv[4], w, h, px.data()) ? 0 : 1; }\n' % ROOT)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(tmp_path / "t"), str(src)])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "png_files.npz"))
+    cases = pngwritecases.cases()
+    assert sorted(cases) == sorted(gold.files)
+    ref = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
+    live = ctypes.CDLL(ref) if os.path.exists(ref) else None
+    for name, img in cases.items():
+        raw, out = tmp_path / "in.raw", tmp_path / "out.png"
+        raw.write_bytes(img.tobytes())
+        subprocess.check_call([str(tmp_path / "t"), str(img.shape[1]), str(img.shape[0]), str(raw), str(out)])
+        got = out.read_bytes()
+        assert got == gold[name].tobytes(), name
+        if live is not None:
+            lp = tmp_path / "live.png"
+            live.stbi_write_png.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+            assert live.stbi_write_png(str(lp).encode(), img.shape[1], img.shape[0], 3, img.ctypes.data, img.shape[1] * 3) == 1
+            assert got == lp.read_bytes(), name
+        # and it is a PNG of those pixels (the big frames: the first rows are enough here)
+        h, w = img.shape[:2]
+        n = 4 if h * w > 4000 else h
+        pw, ph, dec = _png_rgb8_pixels(got, max_rows=n)
+        assert (pw, ph) == (w, h) and np.array_equal(dec, img.reshape(h, w * 3)[:n].astype(np.int64)), name
 
 
 def test_hdr_writer_matches_savehdr_bytes(tmp_path):
