@@ -138,7 +138,15 @@ def cpu_baseline(scene, iters):
                              sample="3 iterations, %.1f s, the reference's intersections.h / interactions.h built host-only (oracle/_ref)" % rdt)
         except Exception as e:                      # the baseline is optional, the bench line is not
             reference = dict(error=str(e)[:200])
-    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port", reference=reference, all_cores=all_cores,
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, cpu_model=cpu_model, host_cores_usable=ncores, kind="port", reference=reference, all_cores=all_cores,
                 stream_compaction_ms_per_iteration=dict(elements=sum(counts), **ms),
                 sample="%d iteration(s) of the same 1920x1080 depth-8 frame, %.1f s, single thread (oracle/pt_oracle.c, gcc -O2)" % (iters, dt),
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
