@@ -357,6 +357,22 @@ def test_full_size_c5_against_oracle(gpu_product, O):
     T.close()
 
 
+def test_8k_frame_against_oracle(gpu_product, O):
+    """A frame far beyond BASELINE's sizes -- 7680x4320, 33 M primary rays, where the per-iteration buffers leave room for
+    one iteration per launch set only (no batching, no lanes: the plain path) -- two iterations against the oracle
+    (16 threads, about 7 s): identical image and rays per bounce."""
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", (7680, 4320), 8)
+    O.set_threads(16)
+    try:
+        O.iterate(1); O.iterate(2)
+    finally:
+        O.set_threads(1)
+    T.render(1, 2)
+    assert beq(T.read_image(), O.image())
+    assert T.stats()["rays_per_bounce"] == O.live_counts().tolist() and T.stats()["rays_per_bounce"][0] == 7680 * 4320
+    T.close()
+
+
 def test_c5_with_the_20k_triangle_mesh_against_oracle(gpu_product, O):
     """Config 5's scene with the 20 448-triangle stand-in at 1920x1080 (the oracle's loop over all faces for every ray sets
     the size: 5.5 M ray-bounces x 20 448 triangles, 16 threads, about 20 s): the BVH + split mesh search on the GPU give the image
