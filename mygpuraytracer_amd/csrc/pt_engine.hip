@@ -1579,8 +1579,9 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->kmax = kmax;
     // three launch sets in flight (one per stream) unless told otherwise: k_move of one overlaps k_bounce of another and
     // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per
-    // iteration); needs the per-iteration radiance buffers (kmax > 1)
-    t->lanes = kmax > 1 ? (opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3) : 1;
+    // iteration); also with one iteration per launch set, i.e. frames so large that only one fits the memory rule above
+    // (7680 x 4320: 6.2 -> 4.75 ms per iteration); needs the per-iteration radiance buffers
+    t->lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
@@ -1600,7 +1601,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
-    if (kmax > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * nseg));
+    if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * nseg));
     {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull) and a
         // queue entry per (ray, mesh) pair in the worst case
         int nmesh = 0;
