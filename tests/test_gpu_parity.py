@@ -581,6 +581,56 @@ def test_render_ahead_is_invisible(gpu_product, scene, opt, res):
         same()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_render_ahead_random_call_sequences(gpu_product, seed):
+    """Random walks over the call surface -- next iteration, a jump, the same camera again, a new camera, a bulk render, a
+    strided render, an image reset, a preview, switching render-ahead off and on -- on a plain tracer and on one with
+    render-ahead, in step: same image bits and statistics wherever the walk looks."""
+    pt = gpu_product
+    rng = np.random.default_rng(seed)
+    scene = ["cornellObj.txt", "cornell.txt", "cornellGlass.txt"][seed % 3]
+    opt = dict(antialiasing=0) if scene == "cornell.txt" else {}
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(96, 72), depth=5)
+    s.apply_runcuda_camera()
+    orbit = s.orbit_init()
+    with pt.Tracer(s, **opt) as A, pt.Tracer(s, **opt) as B:
+        B.set_render_ahead(True)
+        it = 0
+        for step in range(260):
+            r = rng.random()
+            if r < 0.62:
+                it += 1
+                A.pathtrace(it); B.pathtrace(it)
+            elif r < 0.68:
+                it += int(rng.integers(2, 50))
+                A.pathtrace(it); B.pathtrace(it)
+            elif r < 0.73:
+                A.set_camera(s); B.set_camera(s)
+            elif r < 0.78:
+                s.orbit_events(orbit, [("left", float(rng.integers(-30, 30)), float(rng.integers(-10, 10)))])
+                A.set_camera(s); B.set_camera(s)
+            elif r < 0.83:
+                n = int(rng.integers(1, 70))
+                A.render(it + 1, n); B.render(it + 1, n)
+                it += n
+            elif r < 0.86:
+                n = int(rng.integers(1, 9))
+                A.render(it + 1, n, stride=3); B.render(it + 1, n, stride=3)
+                it += 3 * n
+            elif r < 0.89:
+                A.reset_image(); B.reset_image()
+            elif r < 0.93:
+                assert np.array_equal(A.pbo(max(it, 1)), B.pbo(max(it, 1)))
+            elif r < 0.96:
+                B.set_render_ahead(bool(rng.integers(0, 2)))
+            else:
+                sa, sb = A.stats(), B.stats()
+                assert sa["rays_total"] == sb["rays_total"] and sa["rays_per_bounce"] == sb["rays_per_bounce"] and sa["iterations"] == sb["iterations"]
+                assert beq(A.read_image(), B.read_image())
+        assert beq(A.read_image(), B.read_image())
+        assert A.stats()["rays_total"] == B.stats()["rays_total"]
+
+
 def test_strided_render_and_checkpoint_resume(gpu_product, tmp_path):
     """ptx_render_strided traces exactly the iterations it names (each equal to that iteration traced alone), with and
     without batching; a checkpoint written mid-way and resumed in a fresh tracer ends bit-identical to the straight run."""
