@@ -631,6 +631,47 @@ def test_render_ahead_random_call_sequences(gpu_product, seed):
         assert A.stats()["rays_total"] == B.stats()["rays_total"]
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_call_sequences_across_launch_plans(gpu_product, seed):
+    """The same random walk of render / strided render / single iterations / resets on three execution plans -- one
+    iteration at a time on one stream, the default (batches on three streams, short runs cut per lane), and an odd one
+    (batches of 5 on four streams) -- ends in the same bits and counts at every look."""
+    pt = gpu_product
+    rng = np.random.default_rng(100 + seed)
+    scene, opt = [("cornellObj.txt", {}), ("cornell.txt", dict(antialiasing=0)), ("cornellSpaceship.txt", dict(depth_of_field=1)),
+                  ("cornellGlass.txt", dict(sort_by_material=0))][seed]
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(120, 80), depth=6)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, batch=1, lanes=1, **opt) as A, pt.Tracer(s, **opt) as B, pt.Tracer(s, batch=5, lanes=4, **opt) as C:
+        it = 0
+        for step in range(60):
+            r = rng.random()
+            if r < 0.45:
+                n = int(rng.integers(1, 120))
+                for T in (A, B, C):
+                    T.render(it + 1, n)
+                it += n
+            elif r < 0.6:
+                n, stride = int(rng.integers(1, 30)), int(rng.integers(2, 5))
+                for T in (A, B, C):
+                    T.render(it + 1, n, stride=stride)
+                it += n * stride
+            elif r < 0.8:
+                it += 1
+                for T in (A, B, C):
+                    T.pathtrace(it)
+            elif r < 0.85:
+                for T in (A, B, C):
+                    T.reset_image()
+            else:
+                a = A.read_image()
+                assert beq(a, B.read_image()) and beq(a, C.read_image())
+                assert A.stats()["rays_total"] == B.stats()["rays_total"] == C.stats()["rays_total"]
+        a = A.read_image()
+        assert beq(a, B.read_image()) and beq(a, C.read_image())
+        assert A.stats()["rays_per_bounce"] == B.stats()["rays_per_bounce"] == C.stats()["rays_per_bounce"]
+
+
 def test_strided_render_and_checkpoint_resume(gpu_product, tmp_path):
     """ptx_render_strided traces exactly the iterations it names (each equal to that iteration traced alone), with and
     without batching; a checkpoint written mid-way and resumed in a fresh tracer ends bit-identical to the straight run."""
