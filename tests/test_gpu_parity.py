@@ -530,7 +530,9 @@ def test_two_launch_sets_in_flight_identical(gpu_product, scene, opt):
 
 
 @pytest.mark.parametrize("scene,opt,res", [("cornellObj.txt", {}, (200, 120)), ("cornell.txt", dict(antialiasing=0), (160, 160)),
-                                           ("cornellSpaceship.txt", dict(depth_of_field=1), (96, 54))])
+                                           ("cornellSpaceship.txt", dict(depth_of_field=1), (96, 54)),
+                                           ("cornellObj.txt", dict(tile_rows=8, tile_rank=1, tile_world=3), (160, 96)),
+                                           ("cornellGlass.txt", dict(apps_variant=1, sort_by_material=0), (128, 72))])
 def test_render_ahead_is_invisible(gpu_product, scene, opt, res):
     """ptx_set_render_ahead: one ptx_iterate per call (the reference's pathtrace(iter) loop) served from batches traced in
     the background gives, after EVERY call, the bits, ray counts and iteration count of the plain call-by-call tracer --
