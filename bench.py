@@ -277,8 +277,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # W untimed warm-up steps -- and, when those are over in less than 150 ms, further untimed steps until 150 ms have passed:
+    # the GPU needs about 100 ms of work to reach its clocks (50 timed steps after 10 warm-up steps: 0.32 ms per step; after
+    # the ramp: 0.285).  Untimed either way; how many were added is reported as config.clock_warmup_steps.
+    t_warm = time.perf_counter()
     T.render(1, args.warmup)
     T.synchronize()
+    clock_warmup_steps = 0
+    while time.perf_counter() - t_warm < 0.15:
+        T.render(10_000_000 + clock_warmup_steps, 36)
+        T.synchronize()
+        clock_warmup_steps += 36
     if dist_on:                                     # warm the collective too
         reduce_frame(image.clone())
     rays0 = T.stats()["rays_total"]
@@ -335,7 +344,7 @@ def main():
     out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
-               config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb,
+               config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
                            parallelism=("1 GPU" if world == 1 else
                                         "%d ranks taking turns over the iterations of the full frame + 1 RCCL reduce/run" % world if by_iter else
                                         "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL %s/run" % (world, multigpu.TILE_ROWS, args.exchange))),
