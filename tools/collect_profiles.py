@@ -17,9 +17,9 @@ def main(tag, d_stats, d_fetch, d_write):
     os.makedirs(out, exist_ok=True)
     newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun_out/ keeps earlier calls' files too
     shutil.copy(newest(os.path.join(d_stats, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats.csv" % tag))
-    d_stats2 = d_stats.rstrip("/") + "2"           # the default command (two launch sets in flight), when profiled as well
+    d_stats2 = d_stats.rstrip("/") + "2"           # the default command (three launch sets in flight), when profiled as well
     if glob.glob(os.path.join(d_stats2, "*", "*_kernel_stats.csv")):
-        shutil.copy(newest(os.path.join(d_stats2, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats_default_2lanes.csv" % tag))
+        shutil.copy(newest(os.path.join(d_stats2, "*", "*_kernel_stats.csv")), os.path.join(out, "%s_kernel_stats_default_3lanes.csv" % tag))
     acc = {}
     for kind, d in (("fetch", d_fetch), ("write", d_write)):
         f = newest(os.path.join(d, "*", "*_counter_collection.csv"))

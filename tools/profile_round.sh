@@ -9,7 +9,7 @@ rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_writ
 # kernels back to back (--lanes 1): per-kernel durations comparable with the hipEvent figures of bench.py's roofline leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --lanes 1 > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_stats.err
 echo "stats pass done"
-# the default command (two launch sets in flight: kernels overlap, their durations stretch)
+# the default command (three launch sets in flight: kernels overlap, their durations stretch)
 rm -rf $R/gpurun_out/prof_stats2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats2 -- python3 $R/bench.py > $R/gpurun_out/prof_bench2.json 2> $R/gpurun_out/prof_stats2.err
 echo "stats pass (default command) done"
