@@ -211,6 +211,21 @@ def main():
                     "because a kernel's duration is only meaningful when it has the GPU to itself)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher (no RANK in the environment): start the N ranks ourselves, as a CHILD
+    # process (never an exec) and before anything here has touched the GPU, and hand on rank 0's JSON line and the exit code.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("PTX_BENCH_DIST") != "1":
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d (or run `python bench.py --gpus %d`, which "
+                 "starts the ranks itself)" % (args.gpus, os.environ.get("WORLD_SIZE", "1 (unset)"), args.gpus, args.gpus))
+
     import torch
     import torch.distributed as dist
     import mygpuraytracer_amd as pt
@@ -256,6 +271,7 @@ def main():
     scene.apply_runcuda_camera()
     W, H = RES
     image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
+    torch.cuda.current_stream(device).synchronize()      # the tracer uses a stream of its own: the fill must have landed first
     kw = dict(device=dev_index, lanes=args.lanes)
     by_iter = world > 1 and args.shard == "iterations"
     if world > 1 and not by_iter:
@@ -323,16 +339,33 @@ def main():
         units = rays_leg * (rpb[0] / max(sum(rpb), 1)) / max(dom_n, 1)
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
     achieved = BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC counters need rocprofv3, so they are NOT measured in this run: they come from the
+    # committed profile of the same command (tools/profile_round.sh -> profiles/traffic_latest.json), scaled from that
+    # profile's rays per launch to this run's, and are labelled as such.
+    traffic = traffic_source = physical = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
-            traffic = json.load(open(tj)).get(dominant)
+            tjd = json.load(open(tj))
+            per_launch = tjd.get(dominant)
+            ref_units = (tjd.get("_units_per_launch") or {}).get(dominant)
+            if per_launch is not None:
+                traffic = per_launch * (units / ref_units) if ref_units else per_launch
+                traffic_source = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --lanes 1`, "
+                                  "not this run; %s)" % ("scaled by rays per launch %.3g / %.3g" % (units, ref_units) if ref_units
+                                                         else "per launch of that profile, unscaled"))
+                if avg_s > 0:
+                    physical = dict(GBps=traffic / avg_s / 1e9, frac=traffic / avg_s / HBM_PEAK,
+                                    bytes_per_unit=traffic / max(units, 1))
         except Exception:
             traffic = None
     loop_achieved = BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
     roofline = dict(bound="hbm", kernel=dominant, achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=achieved / HBM_PEAK, traffic=traffic,
+                    frac=achieved / HBM_PEAK, traffic=traffic, traffic_source=traffic_source,
+                    # what the kernel physically moves (PMC bytes / measured launch time): it is not HBM-bound in practice --
+                    # `achieved`/`frac` are the contract's algorithmic bytes (reference record sizes)
+                    physical=physical, bound_in_practice="VALU issue + latency (bit-exact IEEE arithmetic), see DESIGN.md 5",
+                    effective_vs_reference_layout=dict(bytes_per_unit=BYTES_BOUNCE_KERNEL, GBps=achieved / 1e9, frac=achieved / HBM_PEAK),
                     avg_launch_us=avg_s * 1e6, launches=dom_n, units_per_launch=units,
                     algorithmic_bytes_per_unit=BYTES_BOUNCE_KERNEL,
                     loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / (HBM_PEAK * world), bytes_per_ray=BYTES_LOOP,

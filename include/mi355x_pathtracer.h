@@ -150,7 +150,9 @@ void ptx_orbit_apply(ptx_scene *s, const ptx_orbit *o);                         
 /* ---- tracer ------------------------------------------------------------------------------------------------ */
 /* pathtraceInit.  external_image: optional device buffer of W*H*3 floats to accumulate into (caller keeps
  * ownership, e.g. a torch tensor that is later reduced over RCCL); NULL = the tracer allocates and zeroes one.
- * stream: optional hipStream_t to run on; NULL = the tracer creates its own. */
+ * stream: optional hipStream_t to run on; NULL = the tracer creates its own (non-blocking) stream.
+ * Ordering is the caller's: whatever initialised external_image (a fill, a checkpoint copy) must have COMPLETED, or have
+ * been issued on `stream`, before the first render call -- the tracer's stream does not wait for other streams. */
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
                const ptx_camera *camera, int trace_depth, const ptx_options *options,
                float *external_image, void *stream, ptx_tracer **out);

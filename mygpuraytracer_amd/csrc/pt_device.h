@@ -242,7 +242,11 @@ struct DScene {
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
 };
 
-PT_DEV int sceneLdsWords(const DScene &sc) { return (sc.ntri_lds * 27 + sc.nmats * 11 + sc.ngeoms * 58 + 3) & ~3; }
+// Words of dynamic LDS the staged scene tables take (tri9 + faces + fnorm = 27 per staged triangle, 11 per material, gtab 40 +
+// cnorm 18 per geom), rounded to 16 bytes.  ONE definition for the kernels and for the host that sizes their launches: what
+// follows the tables holds 64-bit LDS atomics, so the two must never disagree about where it starts.
+__host__ __device__ constexpr int sceneTableWords(int ntri_lds, int nmats, int ngeoms) { return (ntri_lds * 27 + nmats * 11 + ngeoms * 58 + 3) & ~3; }
+PT_DEV int sceneLdsWords(const DScene &sc) { return sceneTableWords(sc.ntri_lds, sc.nmats, sc.ngeoms); }
 constexpr int GTAB_WORDS = 40;
 
 // dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]

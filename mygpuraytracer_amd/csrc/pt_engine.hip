@@ -60,6 +60,9 @@ constexpr int MAX_LANES = 4;     // launch sets in flight at most (ptx_options.l
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
 #endif
+#ifndef PT_PIPELINE_INPUT
+#define PT_PIPELINE_INPUT 0
+#endif
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4     // waves per SIMD k_bounce is compiled for (register budget 512 / this)
 #endif
@@ -68,6 +71,17 @@ constexpr int WAVES = TILE / 64;
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
 // tileIntersect's 2 x 4 list counters
 constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8) + 3) & ~3; }
+// k_bounce's dynamic LDS, in words: [scene tables][head][17 x TILE records].  The record buffer doubles as tileIntersect's
+// scratch, whose 64-bit minimum keys (best[], at word 6*TILE of it) are the target of ds_min_u64: a 4-byte-misaligned
+// 64-bit LDS atomic is a memory aperture violation (that is the fault of gpurun_out/bench11.log, round 1: a head of
+// 2*WAVES*nb + 4*nb + 1 words put the records on an odd word, group_seg_size 20596 B = 5149 words).  Hence every part is a
+// multiple of 4 words, the layout has this one definition for host and device, and the asserts below pin it.
+constexpr int REC_WORDS = 17 * TILE;
+__host__ __device__ constexpr size_t bounceLdsWords(int tableWords, int nb) { return (size_t)tableWords + (size_t)ldsHeadWords(nb) + REC_WORDS; }
+static_assert(ldsHeadWords(1) % 4 == 0 && ldsHeadWords(2) % 4 == 0 && ldsHeadWords(3) % 4 == 0 && ldsHeadWords(7) % 4 == 0 &&
+              ldsHeadWords(45) % 4 == 0 && ldsHeadWords(65535) % 4 == 0, "record buffer must start 16-byte aligned");
+static_assert(sceneTableWords(1, 1, 1) % 4 == 0 && sceneTableWords(12, 7, 7) % 4 == 0 && sceneTableWords(0, 3, 5) % 4 == 0, "scene tables end 16-byte aligned");
+static_assert((6 * TILE) % 2 == 0 && (8 * TILE) % 2 == 0, "tileIntersect's 64-bit keys and lists must be 8-byte aligned inside the record buffer");
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order before k_move sorts it.
@@ -405,13 +419,32 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
 #else
 #define STAMP(k) do { } while (0)
 #endif
+    // Later bounces read their input records through a software pipeline: tile t+1's fields are requested right after tile
+    // t's intersection, so that their HBM latency passes behind t's classification, ranking and stage write instead of
+    // standing in front of t+1's shading (in-kernel stamps: 12 % of the wave time was that wait).  The index is clamped, not
+    // guarded: lanes past the end fetch the last record and ignore it.
+    constexpr bool PIPE = PT_PIPELINE_INPUT && !FIRST && MODE != 2;
+    struct InRec { float f[14]; int32_t pix, mg, idx; };
+    InRec nxt;
+    auto fetch = [&](int tile_, InRec &r) {
+        const PathSoA in = soa_fresh(in_k);
+        const int j = min(tile_ * TILE + tid, n_in - 1);
+#pragma unroll
+        for (int k = 0; k < 12; k++) r.f[k] = in.field(k)[j];
+        r.f[12] = r.f[13] = 0.f;
+        if (p.uses_uv) { r.f[12] = in.u()[j]; r.f[13] = in.v()[j]; }
+        r.pix = in.pix()[j]; r.mg = in.mg()[j]; r.idx = in.idx()[j];
+    };
+    if (PIPE && tile0 < tile1) fetch(tile0, nxt);
     for (int tile = tile0; tile < tile1; tile++) {
 #ifdef PT_STAMPS
         st_t0 = __builtin_amdgcn_s_memtime();
 #endif
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
-        const PathSoA in = soa_fresh(in_k), stage = soa_fresh(stage_k);      // field addresses are formed where they are used
+        InRec cur;
+        if (PIPE) cur = nxt;
+        const PathSoA stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
         int pix = 0;
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
@@ -435,18 +468,18 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                const vec3 intersect = V3(in.px()[i], in.py()[i], in.pz()[i]);     // stored as origin + t * direction
-                ps.d = V3(in.dx()[i], in.dy()[i], in.dz()[i]);
-                ps.color = V3(in.cr()[i], in.cg()[i], in.cb()[i]);
-                pix = in.pix()[i];
+                if (!PIPE) fetch(tile, cur);
+                const vec3 intersect = V3(cur.f[0], cur.f[1], cur.f[2]);           // stored as origin + t * direction
+                ps.d = V3(cur.f[3], cur.f[4], cur.f[5]);
+                ps.color = V3(cur.f[6], cur.f[7], cur.f[8]);
+                pix = cur.pix;
                 Hit h;
                 h.t = 1.f;
-                h.n = V3(in.nx()[i], in.ny()[i], in.nz()[i]);
-                h.u = 0.f; h.v = 0.f;
-                if (p.uses_uv) { h.u = in.u()[i]; h.v = in.v()[i]; }
-                int mg = in.mg()[i];
+                h.n = V3(cur.f[9], cur.f[10], cur.f[11]);
+                h.u = cur.f[12]; h.v = cur.f[13];
+                const int mg = cur.mg;
                 h.mat = mg & 0xffff; h.geom = mg >> 16;
-                const int sidx = in.idx()[i];
+                const int sidx = cur.idx;
 #ifdef PT_STAMPS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 STAMP(11);
@@ -470,6 +503,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             uint32_t mesh_cand = 0;
             if (MODE == 1) {
                 tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
+                if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
                 // park the ray and queue its mesh candidates: per mesh present in the wave one atomic for the base
                 if (i < n_in) {
                     stage.px()[i] = ray.o.x; stage.py()[i] = ray.o.y; stage.pz()[i] = ray.o.z;
@@ -508,6 +542,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             }
         }
         STAMP(1);        // intersect
+        if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
             if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
@@ -1136,8 +1171,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const size_t seg0 = (size_t)lane * t->kmax;
     const int nb = t->nbins;
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
-    const int triWords = t->tri_lds ? ((ntri_lds * 27 + t->nmats * 11 + t->ngeoms * 58 + 3) & ~3) : 0;
-    const size_t lds_bounce = sizeof(int32_t) * ((size_t)triWords + (size_t)ldsHeadWords(nb) + 17 * TILE);
+    const int triWords = t->tri_lds ? sceneTableWords(ntri_lds, t->nmats, t->ngeoms) : 0;
+    const size_t lds_bounce = sizeof(int32_t) * bounceLdsWords(triWords, nb);
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
@@ -1483,6 +1518,21 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // per CU (160 KB LDS, ~19 KB of sort buffers) -- otherwise they are read from global memory (L2-resident)
     t->tri_lds = (((size_t)nmaterials * 11 + (size_t)ngeoms * 58) * 4 <= 56 * 1024 && !opt.no_lds_triangles) ? 1 : 0;
     t->ntri_lds = (t->tri_lds && ((size_t)t->ntri * 27 + (size_t)nmaterials * 11 + (size_t)ngeoms * 58) * 4 <= 56 * 1024) ? t->ntri : 0;
+    {   // k_bounce's dynamic LDS grows with the scene (tables) and with the number of material bins (ranking histogram):
+        // check it against the device limit here, where the caller can be told, not at the first launch.  Step down first
+        // (triangle tables, then all tables, to global memory: the plain per-ray loop over the geoms takes over), refuse
+        // only what cannot run at all.
+        const size_t limit = prop.sharedMemPerBlock;
+        auto need = [&]() { return sizeof(int32_t) * bounceLdsWords(t->tri_lds ? sceneTableWords(t->ntri_lds, nmaterials, ngeoms) : 0, t->nbins); };
+        if (need() > limit && t->ntri_lds) t->ntri_lds = 0;
+        if (need() > limit && t->tri_lds) t->tri_lds = 0;
+        if (need() > limit) {
+            set_error(PTX_ERR_UNSUPPORTED, "material sort over " + std::to_string(t->nbins) + " materials needs " + std::to_string(need()) +
+                      " bytes of LDS per workgroup, the device offers " + std::to_string(limit) + ": render with sort_by_material = 0 (same image "
+                      "only if the reference is built with SORT_BY_MATERIAL 0 too)");
+            return fail(PTX_ERR_UNSUPPORTED);
+        }
+    }
     // per-geom table for the per-lane gathers (rows 0-2 of the three matrices) and conservative world boxes
     std::vector<float> hgtab((size_t)std::max(ngeoms, 1) * 40, 0.f), haabb((size_t)std::max(ngeoms, 1) * 8, 0.f);
     for (int i = 0; i < ngeoms; i++) {
@@ -1576,6 +1626,19 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         kmax = (int)std::min<long long>(want, std::max<long long>(1, (16LL << 30) / (400LL * owned)));
     }
     if (kmax > 64) kmax = 64;
+    // the per-tile prefix tables grow with bins x tiles x iterations in flight: keep them under 4 GiB by putting fewer
+    // iterations into a launch set, then fewer launch sets in flight
+    {
+        const int want_lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
+        auto counts_bytes = [&](int k, int l) { return sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * (size_t)k * l; };
+        while (counts_bytes(kmax, want_lanes) > (4ULL << 30) && kmax > 1) kmax /= 2;
+        if (counts_bytes(kmax, want_lanes) > (4ULL << 30)) opt.lanes = t->opt.lanes = 1;
+        if (counts_bytes(kmax, 1) > (4ULL << 30) && opt.lanes == 1) {
+            set_error(PTX_ERR_UNSUPPORTED, "material sort over " + std::to_string(t->nbins) + " materials on " + std::to_string(t->maxTiles) +
+                      " tiles needs more than 4 GiB of prefix tables: render with sort_by_material = 0");
+            return fail(PTX_ERR_UNSUPPORTED);
+        }
+    }
     t->kmax = kmax;
     // three launch sets in flight (one per stream) unless told otherwise: k_move of one overlaps k_bounce of another and
     // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per

@@ -8,7 +8,10 @@
 //     intervals); baseline coefficients are dequantised as they are decoded, progressive ones at the end, both in
 //     16-bit arithmetic (stb_image.h:2180-2228, 2234-2407, 3058-3085);
 //   * the integer IDCT derived from jidctint with 12-bit constants, +512 >> 10 after the column pass and
-//     +65536 + (128 << 17) >> 17 after the row pass (stb_image.h:2392-2490);
+//     +65536 + (128 << 17) >> 17 after the row pass (stb_image.h:2392-2490).  The one-dimensional butterfly, PTJ_IDCT_1D
+//     below, is TRANSCRIBED statement for statement from stb_image's public-domain macro STBI__IDCT_1D
+//     (src/stb_image.h:2396-2432; int64_t in place of int), not re-derived: a lossy format's texels are defined by that
+//     exact sequence of integer operations, so there is nothing to restate differently;
 //   * chroma upsampling by the "3:1" triangle filters, per row pair as the decoder walks down the picture
 //     (stb_image.h:3397-3590, 3840-3880), nearest neighbour for factors other than 2;
 //   * YCbCr -> RGB in 20-bit fixed point with the Cb term of green masked to 16 bits (stb_image.h:3596-3622); frames whose

@@ -57,6 +57,8 @@ def render_distributed(renderer, width, height, iter_first, count, device, reduc
     `device`) and return the number of ray-bounces it traced.  Returns (image on reduce_to or None, total rays).
     """
     image = torch.zeros(width * height * 3, dtype=torch.float32, device=device)
+    if image.is_cuda:       # the tracer works on a stream of its own: the fill above (torch's current stream) must have landed
+        torch.cuda.current_stream(image.device).synchronize()
     rays = renderer(image, iter_first, count)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(image, dst=reduce_to, op=dist.ReduceOp.SUM)

@@ -1028,3 +1028,49 @@ def test_long_run_of_batches_on_two_streams_is_still_sequential(gpu_product):
         with gpu_product.Tracer(s, batch=batch, lanes=lanes) as B:
             B.render(1, 400); B.render(401, 77); B.render(478, 423)
             assert beq(B.read_image(), want) and B.stats()["rays_total"] == rays, (batch, lanes)
+
+
+def _boxed_scene_text(nmat, ngeom, seed):
+    """`nmat` diffuse materials (0 = light) and `ngeom` small cubes / spheres inside a lit room."""
+    rng = np.random.default_rng(seed)
+    text = "".join(MAT % ((m,) + ((1, 1, 1, 0, 0, 0, 0, 0, 0, 5) if m == 0 else tuple(np.round(rng.uniform(0.2, 0.95, 3), 3)) + (0, 0, 0, 0, 0, 0, 0)))
+                   for m in range(nmat)) + CAMERA_BLOCK
+    objs = ["cube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 4 .3 4", "cube\nmaterial %d\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 11 .01 11" % (1 % nmat),
+            "cube\nmaterial %d\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 11 11" % (2 % nmat)]
+    for k in range(3, ngeom):
+        pos = rng.uniform([-4.0, 0.6, -4.0], [4.0, 8.5, 3.0])
+        objs.append(("sphere" if k % 2 else "cube") + "\nmaterial %d\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g" % (
+            (int(rng.integers(0, nmat)),) + tuple(pos) + tuple(rng.uniform(-90, 90, 3)) + tuple(rng.uniform(0.2, 0.8, 3))))
+    return text + "".join("OBJECT %d\n%s\n\n" % (i, o) for i, o in enumerate(objs[:ngeom]))
+
+
+@pytest.mark.parametrize("nmat,ngeom", [(3, 5), (6, 9), (9, 31), (64, 7), (65, 33)])
+def test_lds_layout_for_odd_and_even_table_sizes(gpu_product, O, tmp_path, nmat, ngeom):
+    """The kernels' dynamic LDS = scene tables + ranking head + record buffer, and the record buffer holds 64-bit LDS
+    atomics: whatever the number of materials (bins) and geoms, odd or even, it must start 8-byte aligned (round 1 lost a
+    run to a 4-byte-misaligned ds_min_u64 when the head had an odd number of words)."""
+    s = _scene_from_text(gpu_product, _boxed_scene_text(nmat, ngeom, 7 * nmat + ngeom), tmp_path, res=(72, 48), depth=5)
+    assert s.num_materials == nmat and s.num_geoms == ngeom
+    _vs_oracle(gpu_product, O, s, iters=2)
+    _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
+
+
+def test_scene_tables_beyond_the_lds_budget_step_down(gpu_product, O, tmp_path):
+    """260 geoms: their tables (58 words each) no longer fit next to the record buffer in a workgroup's LDS, so ptx_create
+    leaves them in global memory (plain per-ray loop) instead of failing at the first launch -- same image as the oracle."""
+    s = _scene_from_text(gpu_product, _boxed_scene_text(12, 260, 5), tmp_path, res=(48, 32), depth=4)
+    assert s.num_geoms == 260
+    _vs_oracle(gpu_product, O, s, iters=2)
+
+
+def test_too_many_material_bins_is_refused_at_create(gpu_product, tmp_path):
+    """2000 materials with the material sort on would need more LDS for the ranking histogram than a workgroup can have:
+    ptx_create says so (PTX_ERR_UNSUPPORTED, with the numbers) instead of a launch failure later; with the sort off
+    (one bin) the same scene renders."""
+    s = _scene_from_text(gpu_product, _boxed_scene_text(2000, 6, 9), tmp_path, res=(32, 24), depth=3)
+    with pytest.raises(gpu_product.PathTracerError) as e:
+        gpu_product.Tracer(s)
+    assert "LDS" in str(e.value) and "2000" in str(e.value)
+    with gpu_product.Tracer(s, sort_by_material=0) as T:
+        T.render(1, 2)
+        assert np.isfinite(T.read_image()).all()

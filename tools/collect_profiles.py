@@ -40,7 +40,15 @@ def main(tag, d_stats, d_fetch, d_write):
         detail[k] = dict(launches_sampled=len(f), fetch_size_kib_mean=sum(f) / len(f), write_size_kib_mean=sum(w) / len(w),
                          hbm_read_bytes_per_launch=fb, hbm_write_bytes_per_launch=wb)
     res["_detail"] = detail
-    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 8 --warmup 8 "
+    # rays per launch of the dominant kernel in the profiled command (bench.py scales the bytes to its own launches by it)
+    fb = os.path.join(os.path.dirname(d_fetch.rstrip("/")), "prof_fetch_bench.json")
+    if os.path.exists(fb):
+        try:
+            line = json.loads(open(fb).read().strip().splitlines()[-1])
+            res["_units_per_launch"] = {line["roofline"]["kernel"]: line["roofline"]["units_per_launch"]}
+        except Exception:
+            pass
+    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
                    "--no-cpu-baseline; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
                    "FETCH_SIZE correction (checked in round 1 on k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
                    "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 12 iterations (the default batch at 1080p).")

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condenses the counter passes of tools/pmc_sq.sh into profiles/<tag>_sq_counters.json: per kernel, the mean of every counter
+per launch plus a few derived figures (VALU lane utilisation, share of wave time issuing / waiting, instruction-cache hit rate).
+
+    python tools/collect_sq.py TAG
+"""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = {"k_bounce<false": "k_bounce", "k_bounceILb0": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_bounceILb1": "k_bounce<first>",
+         "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh"}
+
+
+def main(tag):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_?" % tag))):
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                for k, v in NAMES.items():
+                    if k in r["Kernel_Name"]:
+                        acc[v][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        break
+    out = {}
+    for k, cs in acc.items():
+        m = {c: sum(v) / len(v) for c, v in cs.items()}
+        m["_launches_sampled"] = min(len(v) for v in cs.values())
+        d = {}
+        g = m.get
+        if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+            d["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+            d["quad_cycles_per_valu_instruction"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU")
+        if g("SQ_WAVE_CYCLES"):
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if g(c):
+                    d["share_of_wave_cycles_" + c] = g(c) / g("SQ_WAVE_CYCLES")
+            if g("SQ_BUSY_CYCLES"):
+                d["mean_waves_per_simd"] = g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CYCLES") / 4.0 if False else None
+        if g("SQC_ICACHE_REQ"):
+            d["icache_hit_rate"] = g("SQC_ICACHE_HITS", 0.0) / g("SQC_ICACHE_REQ")
+            d["icache_misses_per_launch"] = g("SQC_ICACHE_MISSES", 0.0)
+        m["_derived"] = {a: b for a, b in d.items() if b is not None}
+        out[k] = m
+    out["_how"] = ("rocprofv3 --pmc <8 counters> per pass (tools/pmc_sq.sh), no tracing, -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
+                   "--no-cpu-baseline; means per launch (a k_bounce launch = 12 iterations of one bounce). SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                   "SQ_ACTIVE_INST_* count quad-cycles summed over waves.")
+    p = os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)
+    json.dump(out, open(p, "w"), indent=1, sort_keys=True)
+    for k in ("k_bounce", "k_bounce<first>", "k_move"):
+        if k in out:
+            print(k, json.dumps(out[k]["_derived"]), {c: round(v) for c, v in out[k].items() if not c.startswith("_")})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

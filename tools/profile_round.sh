@@ -13,7 +13,7 @@ echo "stats pass done"
 rm -rf $R/gpurun_out/prof_stats2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats2 -- python3 $R/bench.py > $R/gpurun_out/prof_bench2.json 2> $R/gpurun_out/prof_stats2.err
 echo "stats pass (default command) done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > $R/gpurun_out/prof_fetch_bench.json 2> $R/gpurun_out/prof_fetch.err
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_write.err
 echo "write pass done"
