@@ -205,7 +205,7 @@ def main():
                     help="N > 1, tiles: how rank 0 gets the frame: 'reduce' = one RCCL reduce(SUM) of the full accumulation buffer "
                     "(what north_star prescribes, the default); 'gather' = every rank sends only the rows it owns "
                     "(multigpu.assemble_tiles: 1/N of the bytes per rank, same frame bit for bit)")
-    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
                     help="launch sets in flight (ptx_options.lanes): 0 = library default (3: k_move of one batch of iterations "
                     "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
                     "because a kernel's duration is only meaningful when it has the GPU to itself)")

@@ -98,7 +98,7 @@ typedef struct ptx_options {
                                     lists from conservative world boxes; results are identical either way */
     int32_t no_bvh;              /* 1 = every mesh is searched by the reference's loop over all its faces; 0 = meshes of
                                     24+ faces get a bounding-volume hierarchy (same nearest face, see csrc/pt_bvh.h)      */
-    int32_t lanes;               /* launch sets in flight, each on a stream of its own: 0 = default (3), 1 .. 4 explicit  */
+    int32_t lanes;               /* launch sets in flight, each on a stream of its own: 0 = default (3), 1 .. 8 explicit  */
     int32_t no_mesh_split;       /* 1 = meshes are searched inside the bounce kernel even when they have a BVH; 0 = scenes
                                     with BVH meshes run the mesh search as a kernel of its own between two halves of it   */
 } ptx_options;

@@ -56,7 +56,7 @@ int set_error(int code, const std::string &msg) { g_last_error = msg; return cod
 #ifndef PT_TILE
 #define PT_TILE 256
 #endif
-constexpr int MAX_LANES = 4;     // launch sets in flight at most (ptx_options.lanes)
+constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.lanes)
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
 #endif
@@ -149,6 +149,16 @@ __device__ __forceinline__ void owned_pixel(const TileMap &tm, int i, int &x, in
     y = (k * tm.tile_world + tm.tile_rank) * tm.tile_rows + (r - k * tm.tile_rows);
 }
 
+// global pixel index (x + y*W) of the `slot`-th pixel this device owns.  Paths carry the SLOT, not the pixel: with a
+// row-tile split the per-iteration radiance buffers, like the streams, are then sized and indexed by what the device
+// owns (1/8 of the frame on one of eight ranks), and with one device slot == pixel.
+__device__ __forceinline__ int slot_to_pixel(const TileMap &tm, int slot) {
+    if (tm.tile_world <= 1) return slot;
+    int x, y;
+    owned_pixel(tm, slot, x, y);
+    return x + y * tm.W;
+}
+
 struct BounceParams {
     DScene sc;
     DCamera cam;
@@ -190,13 +200,13 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 // A path that ends adds its radiance to its pixel (finalGather, src/pathtrace.cu:407-416).  Each pixel ends exactly
 // once per iteration, so this is a plain read-modify-write, or -- when several iterations are in flight as
 // segments of one launch -- a plain store into that iteration's buffer.
-__device__ __forceinline__ void deposit(float *image, float *part, int pix, vec3 c, int apps) {
+__device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, int pix, vec3 c, int apps) {
     if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
     if (part) {
         float *px = part + (size_t)pix * 3;
         px[0] = c.x; px[1] = c.y; px[2] = c.z;
     } else {
-        float *px = image + (size_t)pix * 3;
+        float *px = image + (size_t)slot_to_pixel(tm, pix) * 3;
         px[0] += c.x; px[1] += c.y; px[2] += c.z;
     }
 }
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         if (PIPE) cur = nxt;
         const PathSoA stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
-        int pix = 0;
+        int pix = 0, gpix = 0;       // slot among the owned pixels (what the path carries); global pixel (first bounce only)
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             if (FIRST) {
                 int x, y;
                 owned_pixel(p.tm, i, x, y);
-                pix = x + y * p.cam.resx;
+                pix = i;                 // the slot; the pixel is (x, y)
+                gpix = x + y * p.cam.resx;
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 Rng rng; rng.seed(iter, sidx, 0);
                 bool ended = scatterRay(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
-                    deposit(p.image, part, pix, ps.color, p.apps);
+                    deposit(p.tm, p.image, part, pix, ps.color, p.apps);
                     alive = false;
                 }
             }
@@ -545,14 +556,14 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
-            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)pix * 3);
+            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)gpix * 3);
             bool lit = false;
             if (hit.t > 0.0f) {
                 const DMaterial m = getMaterial(p.sc, hit.mat);
                 if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
                     lit = true;
                     vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-                    deposit(p.image, part, pix, c, p.apps);
+                    deposit(p.tm, p.image, part, pix, c, p.apps);
                     if (FIRST && p.emit_count) {
                         const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
                         int k = atomicAdd(p.emit_count, 1);
@@ -819,13 +830,13 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
 // replay of the cached bounce-0 light hits (first-bounce cache, iterations > 1)
 // add != 0: image[pix] += rgb (one iteration at a time); add == 0: store into the per-iteration radiance buffer of each of
 // the nseg segments (batched mode; the buffers were cleared, so bounce-0 misses read as 0)
-__global__ void k_replay_emission(const int32_t *count, const int32_t *pix, const float *rgb, float *dst, size_t seg_stride,
+__global__ void k_replay_emission(TileMap tm, const int32_t *count, const int32_t *pix, const float *rgb, float *dst, size_t seg_stride,
                                   int nseg, int add) {
     int n = *count;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const float r = rgb[k * 3 + 0], g = rgb[k * 3 + 1], b = rgb[k * 3 + 2];
         if (add) {
-            float *px = dst + (size_t)pix[k] * 3;
+            float *px = dst + (size_t)slot_to_pixel(tm, pix[k]) * 3;      // dst = the image (pixels), pix[] holds slots
             px[0] += r; px[1] += g; px[2] += b;
         } else {
             for (int sg = 0; sg < nseg; sg++) {
@@ -849,7 +860,7 @@ __global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const 
         const size_t o = ((size_t)x + (size_t)y * resx) * 3;
         float r = image[o], g = image[o + 1], b = image[o + 2];
         for (int s = 0; s < nseg; s++) {
-            const float *ps = part + seg_part * s + o;
+            const float *ps = part + seg_part * s + (size_t)i * 3;
             r += ps[0]; g += ps[1]; b += ps[2];
         }
         image[o] = r; image[o + 1] = g; image[o + 2] = b;
@@ -1025,13 +1036,13 @@ struct ptx_tracer {
     size_t seg_items = 0;
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
-    size_t totals_bytes = 0, seg_totals = 0, field_stride = 0;
+    size_t totals_bytes = 0, seg_totals = 0, field_stride = 0, seg_part = 0;
     int kmax = 1;                                        // iterations per launch set (segments)
     long long split_min_paths = 1LL << 20;               // ptx_render_strided: smallest launch set a short run is cut into
     int lanes = 1;                                       // launch sets in flight at once, each on a stream of its own with its own
                                                          // kmax segments of every per-iteration buffer (lane 0 = `stream`)
-    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] = `stream`, the others are the tracer's own
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_chain[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t lane_stream[MAX_LANES] = {};      // [0] = `stream`, the others are the tracer's own
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {}, ev_chain[MAX_LANES] = {};
     // Render-ahead for the one-iteration-per-call shape (ptx_iterate = the reference's pathtrace(iter)): lanes 1 and 2 take
     // turns tracing the NEXT kmax iterations into their per-iteration radiance buffers while the caller works the current
     // batch off, one k_gather (+ k_stats) per call on the main stream.  What a call returns is unchanged: the image holds
@@ -1041,7 +1052,7 @@ struct ptx_tracer {
     int ahead_cur = -1, ahead_nxt = -1;                  // lane whose batch is being consumed / lane holding the batch after it
     bool render_ahead = false;
     int last_ahead_lane = -1;                            // != -1: the previous operation was a call served from that lane's batch
-    hipEvent_t ev_ahead0[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}, ev_ahead1[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_ahead0[MAX_LANES] = {}, ev_ahead1[MAX_LANES] = {};
     int uses_uv = 0;
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
@@ -1220,12 +1231,12 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // when primary rays are not jittered, so bounce 0 is skipped (intent of src/pathtrace.cu:492-499,514)
             hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(256), 0, stream, totals(0, 0), seg_totals, K, t->d_cache_totals, 2 * nb);
             if (batched) {
-                const size_t seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
+                const size_t seg_part = t->seg_part;
                 HIPCHECK(hipMemsetAsync(t->d_part + seg0 * seg_part, 0, sizeof(float) * seg_part * (size_t)K, stream));
-                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
+                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->tm, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
                                    t->d_part + seg0 * seg_part, seg_part, K, 0);
             } else {
-                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
+                hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->tm, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
                                    t->d_image, (size_t)0, 1, 1);
             }
             continue;
@@ -1249,7 +1260,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = (size_t)t->cap;
         bp.seg_counts = seg_counts; bp.seg_chunk = seg_chunk; bp.seg_totals = seg_totals;
         bp.stamps = t->d_stamps;
-        bp.seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
+        bp.seg_part = t->seg_part;
         bp.part = batched ? t->d_part + seg0 * bp.seg_part : nullptr;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
@@ -1313,7 +1324,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     if (prev_lane >= 0 && prev_lane != lane) HIPCHECK(hipStreamWaitEvent(stream, t->ev_chain[prev_lane], 0));      // the previous batch's gather + stats
     if (batched)
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
-                           3 * (size_t)t->cam.resx * t->cam.resy, t->d_part + seg0 * 3 * (size_t)t->cam.resx * t->cam.resy, t->d_image);
+                           t->seg_part, t->d_part + seg0 * t->seg_part, t->d_image);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, t->d_totals + seg0 * seg_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, K,
                        seg_totals, t->d_stats, t->d_stats + 64);
     if (t->lanes > 1) HIPCHECK(hipEventRecord(t->ev_chain[lane], stream));
@@ -1368,7 +1379,7 @@ int ahead_start(ptx_tracer *t, int lane, int first) {
 // one iteration of a traced-ahead batch into the image: what the tail of enqueue_batch does for a whole batch
 int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
     const ptx_tracer::Ahead &a = t->ahead[lane];
-    const size_t sg = (size_t)lane * t->kmax + seg, seg_part = 3 * (size_t)t->cam.resx * t->cam.resy;
+    const size_t sg = (size_t)lane * t->kmax + seg, seg_part = t->seg_part;
     HIPCHECK(hipStreamWaitEvent(t->stream, t->ev_ahead1[lane], 0));
     hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, 1,
                        seg_part, t->d_part + sg * seg_part, t->d_image);
@@ -1664,7 +1675,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
-    if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * 3 * npix * nseg));
+    t->seg_part = 3 * (size_t)t->cap;                 // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles
+    if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * t->seg_part * nseg));
     {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull) and a
         // queue entry per (ray, mesh) pair in the worst case
         int nmesh = 0;
@@ -1777,7 +1789,7 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     };
     if (nl > 1) { int rc = fork(); if (rc != PTX_OK) return rc; }
     int batch = 0, prev_lane = -1;
-    bool used[MAX_LANES] = {false, false, false, false};
+    bool used[MAX_LANES] = {};
     for (int k = 0; k < count; batch++) {
         int K = std::min(nl > 1 ? kb : t->kmax, count - k);
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
@@ -2167,6 +2179,11 @@ int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32
     int m = n < cap ? n : cap;
     if (m > 0) {
         HIPCHECK(hipMemcpy(pixel_index, t->d_cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
+        if (t->tm.tile_world > 1)             // paths carry their slot among the owned pixels: report the pixel (x + y*W)
+            for (int k = 0; k < m; k++) {
+                const int slot = pixel_index[k], r = slot / t->tm.W, x = slot - r * t->tm.W, blk = r / t->tm.tile_rows;
+                pixel_index[k] = x + ((blk * t->tm.tile_world + t->tm.tile_rank) * t->tm.tile_rows + (r - blk * t->tm.tile_rows)) * t->tm.W;
+            }
         HIPCHECK(hipMemcpy(stream_idx, t->d_cap + t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
         std::vector<int32_t> mg((size_t)m);
         HIPCHECK(hipMemcpy(mg.data(), t->d_cap + 2 * (size_t)t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
