@@ -201,10 +201,11 @@ def main():
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
                     help="N > 1: 'tiles' = interleaved pixel-row blocks per rank (what north_star prescribes, the default); "
                     "'iterations' = every rank traces the full frame for every N-th iteration (sums to the single-GPU frame)")
-    ap.add_argument("--exchange", default="reduce", choices=["reduce", "gather"],
-                    help="N > 1, tiles: how rank 0 gets the frame: 'reduce' = one RCCL reduce(SUM) of the full accumulation buffer "
-                    "(what north_star prescribes, the default); 'gather' = every rank sends only the rows it owns "
-                    "(multigpu.assemble_tiles: 1/N of the bytes per rank, same frame bit for bit)")
+    ap.add_argument("--exchange", default="gather", choices=["reduce", "gather"],
+                    help="N > 1, tiles: how rank 0 gets the frame, one RCCL collective per run either way: 'gather' (default) = every rank "
+                    "sends only the row blocks it owns (multigpu.assemble_tiles: 1/N of the bytes per rank, point-to-point over the "
+                    "xGMI links into rank 0, no adds; SURVEY 8(e)); 'reduce' = reduce(SUM) of the full accumulation buffers, in which "
+                    "foreign rows are zero -- the same frame bit for bit, N times the bytes")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
                     help="launch sets in flight (ptx_options.lanes): 0 = library default (3: k_move of one batch of iterations "
                     "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
@@ -255,12 +256,12 @@ def main():
         if args.exchange == "gather" and not (world > 1 and args.shard == "iterations"):
             multigpu.assemble_tiles(img, RES[0], RES[1], multigpu.TILE_ROWS, dst=0, via_host=args.backend != "nccl")
         elif args.backend == "nccl":
-            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(img[:RES[0] * RES[1] * 3], dst=0, op=dist.ReduceOp.SUM)
         else:
-            h = img.cpu()
+            h = img[:RES[0] * RES[1] * 3].cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
-                img.copy_(h)
+                img[:RES[0] * RES[1] * 3].copy_(h)
 
     def all_reduce_scalar(value, dtype, op):
         tt = torch.tensor([value], dtype=dtype, device=device if args.backend == "nccl" else "cpu")
@@ -270,7 +271,7 @@ def main():
     scene = pt.Scene(os.path.join(ROOT, "scenes", SCENE), res=RES, depth=DEPTH)
     scene.apply_runcuda_camera()
     W, H = RES
-    image = torch.zeros(W * H * 3, dtype=torch.float32, device=device)
+    image = multigpu.frame_buffer(W, H, world, device)      # W*H*3 floats (+ padding rows when tiled, for the strided-view gather)
     torch.cuda.current_stream(device).synchronize()      # the tracer uses a stream of its own: the fill must have landed first
     kw = dict(device=dev_index, lanes=args.lanes)
     by_iter = world > 1 and args.shard == "iterations"
@@ -311,14 +312,17 @@ def main():
     t0 = time.perf_counter()
     render_steps(args.warmup + 1, args.steps)       # EXACTLY K steps, enqueued back to back on the tracer's stream
     T.synchronize()
-    if dist_on:                                     # one RCCL reduce of the accumulation buffer per run
+    t_render = time.perf_counter() - t0
+    if dist_on:                                     # one RCCL collective on the accumulation buffer per run
         reduce_frame(image)
     barrier()
     dt = time.perf_counter() - t0
     st = T.stats()
     rays = st["rays_total"] - rays0
     loop_ms = T.last_loop_ms()
+    t_render_max = t_render
     if dist_on:
+        t_render_max = float(all_reduce_scalar(t_render, torch.float64, dist.ReduceOp.MAX))
         dt = float(all_reduce_scalar(dt, torch.float64, dist.ReduceOp.MAX))
         rays = int(all_reduce_scalar(rays, torch.int64, dist.ReduceOp.SUM))
 
@@ -378,6 +382,8 @@ def main():
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
                config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
+                           timed_region_ms=dt * 1e3, slowest_rank_render_ms=t_render_max * 1e3,
+                           exchange_and_barrier_ms=(dt - t_render_max) * 1e3 if dist_on else 0.0,
                            parallelism=("1 GPU" if world == 1 else
                                         "%d ranks taking turns over the iterations of the full frame + 1 RCCL reduce/run" % world if by_iter else
                                         "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL %s/run" % (world, multigpu.TILE_ROWS, args.exchange))),

@@ -25,18 +25,41 @@ def owned_rows(height, tile_rows, rank, world):
     return [y for y in range(height) if (y // tile_rows) % world == rank]
 
 
+def padded_rows(height, tile_rows, world):
+    """Rows of a frame buffer padded to whole rounds of `world` blocks of `tile_rows` rows: in such a buffer the blocks of
+    rank r are the strided view blocks[r::world], so packing and unpacking the owned rows need no index tensors."""
+    per_round = tile_rows * world
+    return (height + per_round - 1) // per_round * per_round
+
+
+def frame_buffer(width, height, world, device, tile_rows=TILE_ROWS):
+    """Zeroed accumulation buffer for a row-tile run: `padded_rows` x width x 3 floats.  The tracer gets its data_ptr() as
+    external_image and only ever touches the first height*width*3 floats (the frame); the padding rows stay zero."""
+    return torch.zeros(padded_rows(height, tile_rows, max(world, 1)) * width * 3, dtype=torch.float32, device=device)
+
+
 def assemble_tiles(image, width, height, tile_rows=TILE_ROWS, dst=0, via_host=False):
     """The alternative to the reduce for pixel-row tiles ("gather of disjoint ranges, 7/8 of the bytes, no
     adds"): every rank packs the rows it owns into one contiguous buffer, ``gather`` (RCCL: point-to-point sends over xGMI,
     all seven links into `dst` at once) brings the world's packs to `dst`, which copies each into its rows.  1/world of the
     reduce's bytes per rank.  The frame on `dst` is bit-identical to what reduce(SUM) gives, since foreign rows hold zeros
-    there.  `image` is the flat W*H*3 accumulation buffer; ranks other than `dst` keep theirs unchanged.  via_host: stage
-    through host memory (gloo rehearsal of a GPU run)."""
+    there.  `image` is the flat accumulation buffer: W*H*3 floats, or -- faster -- a `frame_buffer` (padded to whole rounds
+    of blocks: pack = one strided copy, unpack = one strided copy, no index tensors, three launches in all on `dst`).
+    Ranks other than `dst` keep theirs unchanged.  via_host: stage through host memory (gloo rehearsal of a GPU run)."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    comm_dev = torch.device("cpu") if via_host else image.device
+    if image.numel() == padded_rows(height, tile_rows, world) * width * 3:
+        blk = tile_rows * width * 3
+        v = image.view(-1, world, blk)                    # [round][rank][block]
+        pack = v[:, rank, :].contiguous().to(comm_dev)
+        buf = torch.empty((world,) + tuple(pack.shape), dtype=image.dtype, device=comm_dev) if rank == dst else None
+        dist.gather(pack, list(buf.unbind(0)) if rank == dst else None, dst=dst)
+        if rank == dst:
+            v.copy_(buf.permute(1, 0, 2))
+        return image if rank == dst else None
     frame = image.view(height, width * 3)
     rows = [torch.tensor(owned_rows(height, tile_rows, r, world), dtype=torch.long) for r in range(world)]
     most = max(len(r) for r in rows)                      # the last ranks may own one block less: pad the pack
-    comm_dev = torch.device("cpu") if via_host else image.device
     pack = torch.zeros(most, width * 3, dtype=image.dtype, device=comm_dev)
     mine = rows[rank].to(image.device)
     if len(mine):

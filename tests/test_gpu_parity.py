@@ -1063,14 +1063,17 @@ def test_scene_tables_beyond_the_lds_budget_step_down(gpu_product, O, tmp_path):
     _vs_oracle(gpu_product, O, s, iters=2)
 
 
-def test_too_many_material_bins_is_refused_at_create(gpu_product, tmp_path):
-    """2000 materials with the material sort on would need more LDS for the ranking histogram than a workgroup can have:
-    ptx_create says so (PTX_ERR_UNSUPPORTED, with the numbers) instead of a launch failure later; with the sort off
-    (one bin) the same scene renders."""
-    s = _scene_from_text(gpu_product, _boxed_scene_text(2000, 6, 9), tmp_path, res=(32, 24), depth=3)
+def test_too_many_material_bins_is_refused_at_create(gpu_product, O, tmp_path):
+    """6000 materials with the material sort on would need more LDS for the ranking histogram (48 B per bin) than a workgroup
+    can have (160 KB on MI355X): ptx_create says so (PTX_ERR_UNSUPPORTED, with the numbers) instead of a launch failure
+    later; with the sort off (one bin) the same scene renders.  2000 materials (113 KB of LDS per workgroup, past the 64 KB
+    a launch gets without asking) still run and equal the oracle."""
+    s = _scene_from_text(gpu_product, _boxed_scene_text(6000, 6, 9), tmp_path, res=(32, 24), depth=3)
     with pytest.raises(gpu_product.PathTracerError) as e:
         gpu_product.Tracer(s)
-    assert "LDS" in str(e.value) and "2000" in str(e.value)
+    assert "LDS" in str(e.value) and "6000" in str(e.value)
     with gpu_product.Tracer(s, sort_by_material=0) as T:
         T.render(1, 2)
         assert np.isfinite(T.read_image()).all()
+    s2 = _scene_from_text(gpu_product, _boxed_scene_text(2000, 6, 9), tmp_path, res=(32, 24), depth=3)
+    _vs_oracle(gpu_product, O, s2, iters=2)

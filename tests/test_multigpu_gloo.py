@@ -184,6 +184,13 @@ def _worker_gather(rank, world, port, q, W, H, rows):
     img[own] = rng.random((len(own), W * 3), dtype=np.float32) + np.float32(rank)
     a, b = torch.from_numpy(img.reshape(-1).copy()), torch.from_numpy(img.reshape(-1).copy())
     gathered = multigpu.assemble_tiles(a, W, H, rows, dst=0)
+    # the same through a padded frame buffer (strided-view pack and unpack, what bench.py uses)
+    c = multigpu.frame_buffer(W, H, world, "cpu", tile_rows=rows)
+    c[:W * H * 3] = torch.from_numpy(img.reshape(-1).copy())
+    fast = multigpu.assemble_tiles(c, W, H, rows, dst=0)
+    assert (fast is None) == (gathered is None)
+    if fast is not None:
+        assert torch.equal(fast[:W * H * 3], gathered) and not fast[W * H * 3:].any()
     dist.reduce(b, dst=0, op=dist.ReduceOp.SUM)
     q.put((rank, None if gathered is None else gathered.numpy().copy(), b.numpy().copy() if rank == 0 else None, img.reshape(-1)))
     dist.barrier()
