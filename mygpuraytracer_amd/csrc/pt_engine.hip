@@ -456,7 +456,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         if (PIPE) cur = nxt;
         const PathSoA stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
-        int pix = 0, gpix = 0;       // slot among the owned pixels (what the path carries); global pixel (first bounce only)
+        int pix = 0;                 // slot among the owned pixels: what the path carries instead of the pixel index
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
@@ -475,7 +475,6 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 int x, y;
                 owned_pixel(p.tm, i, x, y);
                 pix = i;                 // the slot; the pixel is (x, y)
-                gpix = x + y * p.cam.resx;
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
-            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)gpix * 3);
+            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)slot_to_pixel(p.tm, pix) * 3);
             bool lit = false;
             if (hit.t > 0.0f) {
                 const DMaterial m = getMaterial(p.sc, hit.mat);
