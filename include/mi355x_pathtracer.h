@@ -194,6 +194,34 @@ double ptx_last_loop_ms(ptx_tracer *t);                 /* timer(): bounce loop 
 int ptx_get_stats(ptx_tracer *t, ptx_stats *out);
 int ptx_owned_pixels(const ptx_tracer *t);              /* pixels this tracer generates (tile split)        */
 void *ptx_stream(ptx_tracer *t);
+/* ---- N GPUs of one node, one process (csrc/pt_multi.cpp) ---------------------------------------------------------
+ * No reference counterpart: the reference drives device 0 only (src/preview.cpp:107).  A main.cpp-shaped caller
+ * (src/main.cpp:128-148) uses these instead of ptx_create / ptx_iterate / ptx_read_image: device i of n traces the
+ * interleaved row blocks (y / tile_rows) % n == i as a stream of its own; ptx_multi_assemble copies every device's row
+ * blocks into device[0]'s frame (one strided peer copy per device over xGMI), ptx_multi_read_image = assemble + read.
+ * `devices` may name one ordinal more than once (two tiles on one GPU: how the one-GPU tests exercise it).
+ * tile_rows <= 0 = 8.  Each tile equals the reference's algorithm run on that tile. */
+typedef struct ptx_multi ptx_multi;
+int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *devices, int ndevices, int tile_rows, ptx_multi **out);
+void ptx_multi_destroy(ptx_multi *m);
+int ptx_multi_device_count(const ptx_multi *m);
+ptx_tracer *ptx_multi_tracer(ptx_multi *m, int i);            /* device i's tracer (statistics, kernel timing, ...) */
+int ptx_multi_set_camera(ptx_multi *m, const ptx_camera *camera, int trace_depth);
+int ptx_multi_reset_image(ptx_multi *m);
+int ptx_multi_iterate(ptx_multi *m, int iter);                /* pathtrace(iter) on every device's tile; enqueues, returns */
+int ptx_multi_set_render_ahead(ptx_multi *m, int on);
+int ptx_multi_render(ptx_multi *m, int iter_first, int count);
+int ptx_multi_synchronize(ptx_multi *m);
+int ptx_multi_assemble(ptx_multi *m);                         /* owned row blocks -> device[0]'s frame; waits for them */
+float *ptx_multi_device_image(ptx_multi *m);                  /* device[0]'s frame (complete after ptx_multi_assemble) */
+int ptx_multi_read_image(ptx_multi *m, float *host_rgb);      /* assemble + W*H*3 floats to the host */
+int ptx_multi_read_albedo(ptx_multi *m, float *host_rgb);     /* apps_variant: the devices' rows of the albedo AOV, merged */
+int ptx_multi_get_stats(ptx_multi *m, ptx_stats *out);        /* rays summed over the devices */
+/* Page-lock / release a caller-owned host buffer (the reference's scene->state.image: the destination of its per-iteration
+ * read-back, src/pathtrace.cu:555-556), so that ptx_read_image / ptx_multi_read_image into it are direct DMA. */
+int ptx_pin_host_buffer(void *p, size_t bytes);
+int ptx_unpin_host_buffer(void *p);
+
 /* Optional per-kernel device timing (hipEvents on the tracer's stream around every launch while on).
  * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh (split mesh search only), 3 = k_move.
  * ptx_get_kernel_times returns the sums since it was last called and clears them. */

@@ -14,10 +14,11 @@ from .api import (  # noqa: F401
     Options,
     Scene,
     Tracer,
+    MultiTracer,
     StreamCompaction,
     build_library,
     load_library,
 )
 
-__all__ = ["LIB_PATH", "PathTracerError", "Options", "Scene", "Tracer", "StreamCompaction", "build_library",
+__all__ = ["LIB_PATH", "PathTracerError", "Options", "Scene", "Tracer", "MultiTracer", "StreamCompaction", "build_library",
            "load_library"]

@@ -173,6 +173,23 @@ def load_library():
     L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
     L.ptx_debug_set_capture.restype, L.ptx_debug_set_capture.argtypes = i, [vp, i]
     L.ptx_debug_read_stream.restype, L.ptx_debug_read_stream.argtypes = i, [vp, C.POINTER(i), vp, vp, vp, vp, i]
+    # several devices behind one handle (csrc/pt_multi.cpp)
+    L.ptx_multi_create.restype, L.ptx_multi_create.argtypes = i, [vp, C.POINTER(Options), C.POINTER(C.c_int), i, i, C.POINTER(vp)]
+    L.ptx_multi_destroy.argtypes = [vp]
+    L.ptx_multi_device_count.restype, L.ptx_multi_device_count.argtypes = i, [vp]
+    L.ptx_multi_tracer.restype, L.ptx_multi_tracer.argtypes = vp, [vp, i]
+    L.ptx_multi_set_camera.restype, L.ptx_multi_set_camera.argtypes = i, [vp, C.POINTER(Camera), i]
+    for n in ("ptx_multi_reset_image", "ptx_multi_synchronize", "ptx_multi_assemble"):
+        getattr(L, n).restype, getattr(L, n).argtypes = i, [vp]
+    L.ptx_multi_iterate.restype, L.ptx_multi_iterate.argtypes = i, [vp, i]
+    L.ptx_multi_set_render_ahead.restype, L.ptx_multi_set_render_ahead.argtypes = i, [vp, i]
+    L.ptx_multi_render.restype, L.ptx_multi_render.argtypes = i, [vp, i, i]
+    L.ptx_multi_device_image.restype, L.ptx_multi_device_image.argtypes = vp, [vp]
+    L.ptx_multi_read_image.restype, L.ptx_multi_read_image.argtypes = i, [vp, vp]
+    L.ptx_multi_read_albedo.restype, L.ptx_multi_read_albedo.argtypes = i, [vp, vp]
+    L.ptx_multi_get_stats.restype, L.ptx_multi_get_stats.argtypes = i, [vp, C.POINTER(Stats)]
+    L.ptx_pin_host_buffer.restype, L.ptx_pin_host_buffer.argtypes = i, [vp, C.c_size_t]
+    L.ptx_unpin_host_buffer.restype, L.ptx_unpin_host_buffer.argtypes = i, [vp]
     # stream compaction
     L.sc_cpu_scan.argtypes = [i, vp, vp]
     for n in ("sc_cpu_compact_without_scan", "sc_cpu_compact_with_scan", "sc_efficient_compact", "sc_naive_scan",
@@ -330,6 +347,66 @@ class Scene:
         ci = np.array([c.resolution[0], c.resolution[1], self.iterations, self.trace_depth], np.int32)
         return dict(geom_ints=gints, geom_trs=trs, geom_mats=gm, materials=m, faces=faces, cam_ints=ci, cam_floats=cf,
                     textures=textures)
+
+
+class MultiTracer:
+    """The frame split into interleaved row blocks over several devices of one node, one process (opaque ptx_multi; the C/C++
+    side of the tile split -- include/mi355x_pathtracer.h "N GPUs of one node").  `devices` may repeat an ordinal."""
+
+    def __init__(self, scene, devices, tile_rows=8, options=None, **opt_kw):
+        self.lib = load_library()
+        if self.lib.ptx_device_count() < 1:
+            raise PathTracerError("no HIP device is visible; the path tracer has no CPU path")
+        self.options = options if options is not None else default_options(**opt_kw)
+        devs = (C.c_int * len(devices))(*devices)
+        h = vp()
+        _check(self.lib.ptx_multi_create(scene.h, C.byref(self.options), devs, len(devices), tile_rows, C.byref(h)), "ptx_multi_create")
+        self.h, self.n = h, len(devices)
+        self.width, self.height = scene.resolution
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ptx_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = lambda self: self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render(self, iter_first, count):
+        _check(self.lib.ptx_multi_render(self.h, iter_first, count), "ptx_multi_render")
+
+    def pathtrace(self, iteration):
+        _check(self.lib.ptx_multi_iterate(self.h, iteration), "ptx_multi_iterate")
+
+    def set_render_ahead(self, on=True):
+        _check(self.lib.ptx_multi_set_render_ahead(self.h, 1 if on else 0), "ptx_multi_set_render_ahead")
+
+    def synchronize(self):
+        _check(self.lib.ptx_multi_synchronize(self.h), "ptx_multi_synchronize")
+
+    def assemble(self):
+        _check(self.lib.ptx_multi_assemble(self.h), "ptx_multi_assemble")
+
+    def read_image(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        _check(self.lib.ptx_multi_read_image(self.h, _ptr(out)), "ptx_multi_read_image")
+        return out
+
+    def read_albedo(self):
+        out = np.zeros((self.width * self.height, 3), np.float32)
+        _check(self.lib.ptx_multi_read_albedo(self.h, _ptr(out)), "ptx_multi_read_albedo")
+        return out
+
+    def stats(self):
+        s = Stats()
+        _check(self.lib.ptx_multi_get_stats(self.h, C.byref(s)), "ptx_multi_get_stats")
+        return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations))
 
 
 class Tracer:

@@ -3,6 +3,7 @@
 // print-and-exit error policy (checkCUDAError, src/pathtrace.cu:42-60); the C ABI underneath returns codes.
 #include "pathtrace_api.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +12,8 @@
 namespace {
 Scene *hst_scene = nullptr;          // borrowed, must outlive pathtraceFree (src/pathtrace.cu:91,102)
 ptx_tracer *g_tracer = nullptr;
+ptx_multi *g_multi = nullptr;        // != NULL: several devices (pathtraceDevices()); g_tracer is then device 0's tracer
+void *g_pinned[3] = {nullptr, nullptr, nullptr};      // state.image / state.albedo page-locked for the per-iteration read-back
 ptx_options g_options;
 bool g_options_init = false;
 
@@ -95,18 +98,50 @@ PerformanceTimer &timer() {
     return t;
 }
 
-float PerformanceTimer::getGpuElapsedTimeForPreviousOperation() { return g_tracer ? (float)ptx_last_loop_ms(g_tracer) : 0.f; }
+std::vector<int> &pathtraceDevices() {
+    static std::vector<int> devices;
+    return devices;
+}
+
+float PerformanceTimer::getGpuElapsedTimeForPreviousOperation() {
+    if (!g_tracer) return 0.f;
+    if (!g_multi) return (float)ptx_last_loop_ms(g_tracer);
+    double ms = 0.0;                 // several devices work side by side: the slowest one's bounce loop
+    for (int i = 0; i < ptx_multi_device_count(g_multi); i++) ms = std::max(ms, ptx_last_loop_ms(ptx_multi_tracer(g_multi, i)));
+    return (float)ms;
+}
 
 void pathtraceInit(Scene *scene) {
     hst_scene = scene;
-    check(ptx_create((int)scene->geoms.size(), scene->geoms.data(), (int)scene->materials.size(), scene->materials.data(),
-                     &scene->state.camera, scene->state.traceDepth, &pathtraceOptions(), nullptr, nullptr, &g_tracer),
-          "pathtraceInit");
-    check(ptx_set_render_ahead(g_tracer, pathtraceRenderAhead() ? 1 : 0), "pathtraceInit");
+    const std::vector<int> &devs = pathtraceDevices();
+    if (devs.size() > 1) {
+        // the C ABI's multi-device layer takes the loaded scene: hand it the caller's camera and depth first
+        *ptx_scene_camera(scene->handle()) = scene->state.camera;
+        ptx_scene_set_trace_depth(scene->handle(), scene->state.traceDepth);
+        check(ptx_multi_create(scene->handle(), &pathtraceOptions(), devs.data(), (int)devs.size(), 0, &g_multi), "pathtraceInit");
+        g_tracer = ptx_multi_tracer(g_multi, 0);
+        check(ptx_multi_set_render_ahead(g_multi, pathtraceRenderAhead() ? 1 : 0), "pathtraceInit");
+    } else {
+        ptx_options o = pathtraceOptions();
+        if (devs.size() == 1) o.device = devs[0];
+        check(ptx_create((int)scene->geoms.size(), scene->geoms.data(), (int)scene->materials.size(), scene->materials.data(),
+                         &scene->state.camera, scene->state.traceDepth, &o, nullptr, nullptr, &g_tracer),
+              "pathtraceInit");
+        check(ptx_set_render_ahead(g_tracer, pathtraceRenderAhead() ? 1 : 0), "pathtraceInit");
+    }
+    // the reference copies the whole fp32 frame into scene->state.image after every iteration (src/pathtrace.cu:555-556):
+    // page-lock the destination once, so that each of those copies is one DMA at PCIe rate (not fatal if it cannot be)
+    const size_t bytes = scene->state.image.size() * sizeof(mi355x::vec3);
+    if (bytes && ptx_pin_host_buffer(scene->state.image.data(), bytes) == PTX_OK) g_pinned[0] = scene->state.image.data();
+    if (pathtraceOptions().apps_variant && bytes && scene->state.albedo.size() == scene->state.image.size() &&
+        ptx_pin_host_buffer(scene->state.albedo.data(), bytes) == PTX_OK) g_pinned[1] = scene->state.albedo.data();
 }
 
 void pathtraceFree() {          // safe before init and idempotent, as main.cpp:129 relies on
-    ptx_destroy(g_tracer);
+    for (void *&p : g_pinned) { if (p) ptx_unpin_host_buffer(p); p = nullptr; }
+    if (g_multi) ptx_multi_destroy(g_multi);
+    else ptx_destroy(g_tracer);
+    g_multi = nullptr;
     g_tracer = nullptr;
 }
 
@@ -114,9 +149,18 @@ void pathtrace(void *pbo, int frame, int iter) {
     (void)frame;                 // unused by the reference as well
     if (!g_tracer || !hst_scene) { fprintf(stderr, "pathtrace called before pathtraceInit\n"); exit(EXIT_FAILURE); }
     // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
+    const bool apps = pathtraceOptions().apps_variant != 0;
+    if (g_multi) {               // several devices: every device its tile, then the row blocks into device 0's frame
+        check(ptx_multi_set_camera(g_multi, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
+        check(ptx_multi_iterate(g_multi, iter), "pathtrace");
+        check(ptx_multi_read_image(g_multi, &hst_scene->state.image[0].x), "image readback");      // assemble + :555-556
+        if (!apps) check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");             // from the assembled frame
+        if (apps) check(ptx_multi_read_albedo(g_multi, &hst_scene->state.albedo[0].x), "albedo readback");
+        check(ptx_synchronize(g_tracer), "pathtrace");
+        return;
+    }
     check(ptx_set_camera(g_tracer, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
     check(ptx_iterate(g_tracer, iter), "pathtrace");
-    const bool apps = pathtraceOptions().apps_variant != 0;
     // apps/src builds with AI_DENOISE: no preview from here (sendToGPU shows the denoised frame), the albedo AOV comes back
     // with the image (apps/src/pathtrace.cu:658-669)
     if (!apps) check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");

@@ -72,9 +72,14 @@ ptx_options &pathtraceOptions();
 bool &pathtraceRenderAhead();                           // true (default): pathtrace(iter) calls that count up are served from
                                                         // iterations traced ahead in the background (ptx_set_render_ahead); same results
 
+// Devices the next pathtraceInit uses.  Empty (default) = the current device, as the reference (src/preview.cpp:107).  Two or
+// more ordinals: the frame is split into interleaved 8-row blocks, device i traces blocks i, i + n, ... (ptx_multi_*,
+// include/mi355x_pathtracer.h); pathtrace() still returns with the whole frame in scene->state.image.
+std::vector<int> &pathtraceDevices();
+
 PerformanceTimer &timer();                              // src/pathtrace.h:6
 void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7
 void pathtraceFree();                                   // src/pathtrace.h:8
 void pathtrace(void *pbo, int frame, int iteration);    // src/pathtrace.h:9 (uchar4 *pbo); pbo may be NULL (no preview)
 void sendToGPU(void *pbo, int iter);                    // apps/src/pathtrace.h:10 (uchar4 *pbo): state.output -> 8-bit preview in the device pbo
-ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state
+ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state (device 0's with several devices)

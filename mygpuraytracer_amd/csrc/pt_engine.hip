@@ -1465,7 +1465,16 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     }
     if (t->grid < 1) t->grid = 1;
     if (stream) { t->stream = (hipStream_t)stream; t->own_stream = false; }
-    else { HC(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)); t->own_stream = true; }
+    else {
+        // the main stream carries what a caller waits for (per-call gather, preview, frame read-back) while the other lanes
+        // trace ahead in the background: it gets the highest priority, so that those short kernels are not queued behind
+        // the bounce kernels' workgroups
+        int prio_lo = 0, prio_hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_lo = prio_hi = 0; (void)hipGetLastError(); }
+        if (getenv("PTX_DEBUG_NO_PRIORITY")) prio_hi = prio_lo;
+        HC(hipStreamCreateWithPriority(&t->stream, hipStreamNonBlocking, prio_hi));
+        t->own_stream = true;
+    }
     HC(hipEventCreate(&t->ev_start)); HC(hipEventCreate(&t->ev_stop));
 
     // scene upload (pathtraceInit, src/pathtrace.cu:111-146) -- flattened, no host struct is mutated

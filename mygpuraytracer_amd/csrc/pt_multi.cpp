@@ -1,0 +1,178 @@
+// pt_multi.cpp -- N GPUs of one node behind one handle, one process: the C/C++ side of the row-tile split.
+//
+// The reference is single-GPU (src/preview.cpp:107 cudaGLSetGLDevice(0)); a caller shaped like its main loop
+// (src/main.cpp:128-148: Free, Init, pathtrace(iter) per frame, Free) gets N devices through this layer without touching
+// Python or torch.distributed.  Device i of n traces the interleaved row blocks (y / tile_rows) % n == i of the frame as a
+// stream of its own (ptx_options.tile_*), with its own streams and buffers; nothing is exchanged while tracing.  One
+// exchange per read: the row blocks a device owns are copied into device[0]'s frame with one strided peer copy per device
+// (hipMemcpy2DAsync over xGMI: rows = blocks, pitch = n blocks) -- the gather SURVEY 8(e) names; foreign rows of every
+// device's own buffer stay zero, so an RCCL reduce(SUM) of the buffers would give the same frame bit for bit.
+// Parity: every tile equals the oracle run on that tile (stream indices are local to a tile).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355x_pathtracer.h"
+
+extern "C" void ptx_internal_set_error(const char *msg);
+
+struct ptx_multi {
+    std::vector<ptx_tracer *> tr;
+    std::vector<int> dev;
+    int W = 0, H = 0, tile_rows = 0;
+};
+
+namespace {
+int fail(int code, const std::string &msg) { ptx_internal_set_error(msg.c_str()); return code; }
+#define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+}  // namespace
+
+extern "C" {
+
+int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *devices, int ndevices, int tile_rows, ptx_multi **out) {
+    if (!out) return fail(PTX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!s || !devices || ndevices < 1 || ndevices > 64) return fail(PTX_ERR_INVALID, "ptx_multi_create: need a scene and 1..64 device ordinals");
+    if (tile_rows < 1) tile_rows = 8;
+    const int have = ptx_device_count();
+    if (have < 1) return fail(PTX_ERR_NODEVICE, "no HIP device available; this library has no CPU path");
+    for (int i = 0; i < ndevices; i++)
+        if (devices[i] < 0 || devices[i] >= have) return fail(PTX_ERR_INVALID, "ptx_multi_create: device ordinal out of range");
+    ptx_multi *m = new ptx_multi;
+    const ptx_camera *cam = ptx_scene_camera(const_cast<ptx_scene *>(s));
+    m->W = cam->resolution[0]; m->H = cam->resolution[1]; m->tile_rows = tile_rows;
+    for (int i = 0; i < ndevices; i++) {
+        ptx_options o;
+        if (options) o = *options; else ptx_default_options(&o);
+        o.device = devices[i];
+        if (ndevices > 1) { o.tile_rows = tile_rows; o.tile_rank = i; o.tile_world = ndevices; }
+        ptx_tracer *t = nullptr;
+        int rc = ptx_create_from_scene(s, &o, nullptr, nullptr, &t);
+        if (rc != PTX_OK) {
+            for (ptx_tracer *p : m->tr) ptx_destroy(p);
+            delete m;
+            return rc;                                  // (ptx_last_error() says why)
+        }
+        m->tr.push_back(t); m->dev.push_back(devices[i]);
+    }
+    // peer access device[0] <-> the others, so that the gather is a direct xGMI copy (already-enabled is fine; where it
+    // cannot be enabled the copies still work, staged by the runtime)
+    for (int i = 1; i < ndevices; i++)
+        if (devices[i] != devices[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+                hipSetDevice(devices[i]);
+                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+        }
+    *out = m;
+    return PTX_OK;
+}
+
+void ptx_multi_destroy(ptx_multi *m) {
+    if (!m) return;
+    for (ptx_tracer *t : m->tr) ptx_destroy(t);
+    delete m;
+}
+
+int ptx_multi_device_count(const ptx_multi *m) { return m ? (int)m->tr.size() : 0; }
+ptx_tracer *ptx_multi_tracer(ptx_multi *m, int i) { return (m && i >= 0 && i < (int)m->tr.size()) ? m->tr[i] : nullptr; }
+
+#define FOR_ALL(call) do { if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi"); for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } while (0)
+int ptx_multi_set_camera(ptx_multi *m, const ptx_camera *camera, int trace_depth) { FOR_ALL(ptx_set_camera(t, camera, trace_depth)); }
+int ptx_multi_reset_image(ptx_multi *m) { FOR_ALL(ptx_reset_image(t)); }
+int ptx_multi_render(ptx_multi *m, int iter_first, int count) { FOR_ALL(ptx_render(t, iter_first, count)); }     /* enqueues on every device, returns */
+int ptx_multi_iterate(ptx_multi *m, int iter) { FOR_ALL(ptx_iterate(t, iter)); }
+int ptx_multi_set_render_ahead(ptx_multi *m, int on) { FOR_ALL(ptx_set_render_ahead(t, on)); }
+int ptx_multi_synchronize(ptx_multi *m) { FOR_ALL(ptx_synchronize(t)); }
+
+// the row blocks device i owns -> the same rows of device[0]'s frame; returns when they have arrived
+int ptx_multi_assemble(ptx_multi *m) {
+    if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi");
+    const int n = (int)m->tr.size();
+    if (n == 1) return ptx_synchronize(m->tr[0]);
+    const size_t row_bytes = (size_t)m->W * 3 * sizeof(float), blk_bytes = row_bytes * m->tile_rows;
+    const int nblocks = (m->H + m->tile_rows - 1) / m->tile_rows;
+    char *dst0 = reinterpret_cast<char *>(ptx_device_image(m->tr[0]));
+    for (int i = 1; i < n; i++) {
+        const char *src = reinterpret_cast<const char *>(ptx_device_image(m->tr[i]));
+        hipStream_t st = (hipStream_t)ptx_stream(m->tr[i]);          // behind that device's tracing
+        MHIP(hipSetDevice(m->dev[i]));
+        // blocks i, i + n, i + 2n, ...: the whole ones as one strided copy, a cut-off last block (H not a multiple of
+        // tile_rows) on its own
+        int mine = 0, whole = 0;
+        for (int b = i; b < nblocks; b += n) { mine++; if ((b + 1) * m->tile_rows <= m->H) whole++; }
+        if (whole > 0)
+            MHIP(hipMemcpy2DAsync(dst0 + (size_t)i * blk_bytes, (size_t)n * blk_bytes, src + (size_t)i * blk_bytes, (size_t)n * blk_bytes,
+                                  blk_bytes, (size_t)whole, hipMemcpyDeviceToDevice, st));
+        if (mine > whole) {
+            const int b = i + whole * n;
+            const size_t off = (size_t)b * blk_bytes, bytes = (size_t)(m->H - b * m->tile_rows) * row_bytes;
+            MHIP(hipMemcpyAsync(dst0 + off, src + off, bytes, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    for (ptx_tracer *t : m->tr) { int rc = ptx_synchronize(t); if (rc != PTX_OK) return rc; }
+    return PTX_OK;
+}
+
+float *ptx_multi_device_image(ptx_multi *m) { return m ? ptx_device_image(m->tr[0]) : nullptr; }     /* complete after ptx_multi_assemble */
+
+int ptx_multi_read_image(ptx_multi *m, float *host_rgb) {
+    if (!m || !host_rgb) return fail(PTX_ERR_INVALID, "null argument");
+    int rc = ptx_multi_assemble(m);
+    if (rc != PTX_OK) return rc;
+    return ptx_read_image(m->tr[0], host_rgb);
+}
+
+// apps_variant: every device's albedo AOV holds its own rows of iteration 1; merged on the host (a one-off, 1 frame)
+int ptx_multi_read_albedo(ptx_multi *m, float *host_rgb) {
+    if (!m || !host_rgb) return fail(PTX_ERR_INVALID, "null argument");
+    const int n = (int)m->tr.size();
+    if (n == 1) return ptx_read_albedo(m->tr[0], host_rgb);
+    std::vector<float> tmp((size_t)m->W * m->H * 3);
+    const size_t row = (size_t)m->W * 3;
+    for (int i = 0; i < n; i++) {
+        int rc = ptx_read_albedo(m->tr[i], tmp.data());
+        if (rc != PTX_OK) return rc;
+        for (int y = 0; y < m->H; y++)
+            if ((y / m->tile_rows) % n == i) memcpy(host_rgb + (size_t)y * row, tmp.data() + (size_t)y * row, row * sizeof(float));
+    }
+    return PTX_OK;
+}
+
+// Page-locks a host buffer the caller owns (e.g. the reference's scene->state.image, the destination of its per-iteration
+// frame read-back, src/pathtrace.cu:555-556) so that ptx_read_image copies into it by DMA, without the runtime's staging
+// through its own pinned chunks.  The buffer must not move or be freed while pinned.  Failure is not fatal to the caller:
+// reads into unpinned memory work, slower.
+int ptx_pin_host_buffer(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(PTX_ERR_INVALID, "ptx_pin_host_buffer: null buffer");
+    MHIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return PTX_OK;
+}
+int ptx_unpin_host_buffer(void *p) {
+    if (!p) return PTX_OK;
+    MHIP(hipHostUnregister(p));
+    return PTX_OK;
+}
+
+// rays and iterations summed over the devices (each traces its tile of every iteration: iterations = device 0's), loop time
+// = the slowest device's
+int ptx_multi_get_stats(ptx_multi *m, ptx_stats *out) {
+    if (!m || !out) return fail(PTX_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    for (size_t i = 0; i < m->tr.size(); i++) {
+        ptx_stats s;
+        int rc = ptx_get_stats(m->tr[i], &s);
+        if (rc != PTX_OK) return rc;
+        out->bounces = s.bounces > out->bounces ? s.bounces : out->bounces;
+        for (int b = 0; b < 64; b++) out->rays_per_bounce[b] += s.rays_per_bounce[b];
+        out->rays_total += s.rays_total;
+        if (s.loop_ms_total > out->loop_ms_total) out->loop_ms_total = s.loop_ms_total;
+        if (i == 0) out->iterations = s.iterations;
+    }
+    return PTX_OK;
+}
+
+}  // extern "C"

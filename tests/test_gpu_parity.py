@@ -1077,3 +1077,72 @@ def test_too_many_material_bins_is_refused_at_create(gpu_product, O, tmp_path):
         assert np.isfinite(T.read_image()).all()
     s2 = _scene_from_text(gpu_product, _boxed_scene_text(2000, 6, 9), tmp_path, res=(32, 24), depth=3)
     _vs_oracle(gpu_product, O, s2, iters=2)
+
+
+def _oracle_tiles(O, s, world, tile_rows, iters, **opt):
+    """the frame the oracle assembles from `world` row tiles, each traced as a stream of its own; + total rays"""
+    d = s.dump()
+    O.set_libm(1); O.create(d, d["textures"])
+    O.set_options(aa=opt.get("antialiasing", 1), dof=opt.get("depth_of_field", 0), sort=opt.get("sort_by_material", 1), cache=opt.get("cache_first_bounce", 1))
+    total, rays = None, 0
+    try:
+        for rank in range(world):
+            O.set_tile(tile_rows, rank, world); O.pt_init()
+            for it in range(1, iters + 1):
+                O.iterate(it)
+                rays += int(O.live_counts().sum())
+            total = O.image().copy() if total is None else total + O.image()      # disjoint rows: exact
+    finally:
+        O.set_tile(0, 0, 1)
+    return total, rays
+
+
+@pytest.mark.parametrize("res,devices,tile_rows", [((96, 64), [0, 0], 8), ((100, 60), [0, 0, 0], 8), ((64, 37), [0, 0, 0, 0], 4)])
+def test_several_devices_behind_the_c_abi(gpu_product, O, res, devices, tile_rows):
+    """ptx_multi_*: one process, one tracer per listed device (here the same GPU several times -- what a one-GPU box can
+    check), each tracing its interleaved row blocks; ptx_multi_read_image copies the blocks into device[0]'s frame.  Equals
+    the oracle's tiles assembled, bit for bit, including frames whose height is not a multiple of the block (cut-off last
+    block) and ranks that own one block less; rays summed over the devices."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=res, depth=6)
+    s.apply_runcuda_camera()
+    want, rays = _oracle_tiles(O, s, len(devices), tile_rows, 3)
+    with pt.MultiTracer(s, devices, tile_rows=tile_rows) as M:
+        M.render(1, 2)
+        M.pathtrace(3)
+        img = M.read_image()
+        assert beq(img, want)
+        assert M.stats()["rays_total"] == rays and M.stats()["iterations"] == 3
+        assert beq(M.read_image(), want)                   # assembling twice changes nothing
+    with pt.MultiTracer(s, [0]) as M1, pt.Tracer(s) as T:  # one device: the plain tracer
+        M1.render(1, 3); T.render(1, 3)
+        assert beq(M1.read_image(), T.read_image())
+
+
+def test_cpp_veneer_on_several_devices(gpu_product, O, tmp_path):
+    """The C++ veneer with pathtraceDevices() = {0, 0, 0}: pathtraceInit / pathtrace(pbo, frame, iter) per iteration / Free as
+    in src/main.cpp; state.image after the last call holds the assembled frame = the oracle's three tiles, the device pbo its
+    8-bit preview."""
+    import subprocess
+    pt = gpu_product
+    exe = tmp_path / "veneer_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "veneer_check.cpp"),
+                           "-L" + os.path.join(ROOT, "mygpuraytracer_amd"), "-lmi355x_pathtracer", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mygpuraytracer_amd") + ",-rpath,/opt/rocm/lib"])
+    W, H, D, N = 64, 44, 5, 30
+    scene = os.path.join(ROOT, "scenes", "cornellObj.txt")
+    subprocess.check_output([str(exe), scene, str(W), str(H), str(D), str(N), str(tmp_path / "v"), "devices=0,0,0"], text=True)
+    s = pt.Scene(scene, res=(W, H), depth=D)
+    s.apply_runcuda_camera()
+    want, _ = _oracle_tiles(O, s, 3, 8, N)
+    got = np.frombuffer(open(str(tmp_path / "v") + ".image", "rb").read(), np.float32).reshape(-1, 3)
+    assert beq(got, want)
+    with pt.MultiTracer(s, [0, 0, 0]) as M:
+        M.render(1, N)
+        M.assemble()
+        T0 = pt.Tracer.__new__(pt.Tracer)                 # device 0's tracer of the set, for its preview
+        T0.lib, T0.h, T0.width, T0.height = M.lib, M.lib.ptx_multi_tracer(M.h, 0), W, H
+        pbo = T0.pbo(N)
+        T0.h = None
+    assert np.array_equal(np.frombuffer(open(str(tmp_path / "v") + ".pbo", "rb").read(), np.uint8).reshape(-1, 4), pbo)

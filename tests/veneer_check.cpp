@@ -2,7 +2,7 @@
 // drives its pathtrace.h: Scene, pathtraceFree/Init, pathtrace(pbo, frame, iter) per iteration with a DEVICE pbo, timer(),
 // and, with `apps`, the apps/src extras (state.albedo, sendToGPU).  Writes what it saw to OUT.{image,albedo,pbo,pbo2} for
 // tests/test_gpu_parity.py to compare with the C ABI driven from Python.  Built by the test with g++.
-//   veneer_check SCENE W H DEPTH ITERS OUT [apps]
+//   veneer_check SCENE W H DEPTH ITERS OUT [apps] [devices=0,0,...]
 #include <hip/hip_runtime_api.h>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +21,20 @@ int main(int argc, char **argv) {
     if (argc < 7) return 2;
     const int w = atoi(argv[2]), h = atoi(argv[3]), depth = atoi(argv[4]), iters = atoi(argv[5]);
     const std::string out = argv[6];
-    const bool apps = argc > 7 && std::string(argv[7]) == "apps";
+    bool apps = false;
+    for (int a = 7; a < argc; a++) {
+        const std::string arg = argv[a];
+        if (arg == "apps") apps = true;
+        else if (arg.rfind("devices=", 0) == 0) {          // several devices (an ordinal may repeat): the frame is split into row tiles
+            pathtraceDevices().clear();
+            for (size_t p = 8; p < arg.size();) {
+                size_t e = arg.find(',', p);
+                if (e == std::string::npos) e = arg.size();
+                pathtraceDevices().push_back(atoi(arg.substr(p, e - p).c_str()));
+                p = e + 1;
+            }
+        }
+    }
     Scene *scene = new Scene(argv[1]);
     scene->setResolution(w, h);
     scene->state.traceDepth = depth;
