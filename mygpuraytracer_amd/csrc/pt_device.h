@@ -284,6 +284,13 @@ PT_DEV vec3 cubeNormalTab(const DScene &sc, int g, int side) {
     return V3(gp[0], gp[1], gp[2]);
 }
 
+// type of geom g: from the staged per-geom table when there is one (an LDS read instead of a dependent global load in
+// front of every diffuse scatter)
+PT_DEV int geomType(const DScene &sc, int g) {
+    if (sc.tri_lds) return __float_as_int(reinterpret_cast<const float *>(pt_lds)[sc.ntri_lds * 24 + sc.nmats * 11 + g * 40 + 36]);
+    return sc.geoms[g].type;
+}
+
 // struct Material of material `id` (per-lane id: from LDS when staged, else global memory)
 PT_DEV DMaterial getMaterial(const DScene &sc, int id) {
     DMaterial m;
@@ -895,14 +902,19 @@ PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long ke
             h.n = faceNormalTab(sc, __float_as_int(G[38]) + c.face);
         }
     } else {
-        float invT[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
         if (type == G_CUBE) {   // one of six normals per cube, computed at upload (normalize(invTranspose * +-e_axis))
             const int axis = (int)(aux & 3u) - 1;
             if (axis >= 0) h.n = cubeNormalTab(sc, g, axis * 2 + ((aux & 4u) ? 1 : 0));
-            else h.n = normalize(mulRows(invT, V3(0.f, 0.f, 0.f), 0.0f));    // no axis recorded (NaN inputs): the reference's zero vector
+            else {              // no axis recorded (NaN inputs): the reference's zero vector through the same arithmetic
+                float invT[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
+                h.n = normalize(mulRows(invT, V3(0.f, 0.f, 0.f), 0.0f));
+            }
         } else {            // sphere: the object-space hit point is recomputed (same arithmetic as in primKey)
+            float invT[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
             float inv[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) inv[k] = G[k];
@@ -1031,7 +1043,7 @@ PT_DEV bool scatterRay(const DScene &sc, PathState &ps, vec3 intersect, const Hi
         ps.d = nd;
         ps.color = mul(ps.color, V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]));
         ps.o = add(intersect, scale(nd, 0.01f));
-    } else if (sc.geoms[hit.geom].type == G_OBJ) {
+    } else if (geomType(sc, hit.geom) == G_OBJ) {
         const DGeom &geom = sc.geoms[hit.geom];
         const DTex &kd = geom.tex[0], &ks = geom.tex[1], &ke = geom.tex[2];
         vec3 emission = V3(0.f, 0.f, 0.f);

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             while (remaining) {
                 int leader = __ffsll((long long)remaining) - 1;
-                int b = __shfl(bin, leader);
+                int b = __builtin_amdgcn_readlane(bin, leader);      // (leader is wave-uniform: no LDS round trip as __shfl would make)
                 unsigned long long m_all = __ballot(alive && bin == b);
                 unsigned long long m_scat = __ballot(pending && bin == b);
                 if (alive && bin == b) {

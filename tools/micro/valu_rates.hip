@@ -63,6 +63,18 @@ __global__ __launch_bounds__(256) void k(int trips, float *out, unsigned long lo
         if (OP == 15) { REP8(G8("v_and_b32")) }
         if (OP == 16) { REP8(F8("v_fma_f32") G8("v_mul_f32")) }    // 128 instrs per trip: mixed
         if (OP == 17) { REP8(U8("v_mov_b32")) }
+        if (OP == 18) { REP8(G8("v_min_f32")) }
+        if (OP == 19) { REP8(F8("v_max3_f32")) }
+        if (OP == 20) { REP8(F8("v_cndmask_b32 %0, %0, %1, vcc ; ")) }
+        if (OP == 21) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a0), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a1), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a2), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a3), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a4), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a5), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a6), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a7), "v"(b) : "vcc");) }
+        if (OP == 22) { REP8(F8("v_div_fmas_f32")) }
+        if (OP == 23) { REP8(G8("v_add_u32")) }
+        if (OP == 24) { REP8(F8("v_mad_u32_u24")) }
+        if (OP == 25) { REP8(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d0) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d1) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d2) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d3) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d4) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d5) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d6) : "v"(b), "v"(c) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d7) : "v"(b), "v"(c) : "vcc");) }
+        if (OP == 26) { REP8(asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d0) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d1) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d2) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d3) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d4) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d5) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d6) : "v"(db)); asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d7) : "v"(db));) }
+        if (OP == 27) { REP8(asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(a0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(a1) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(a2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(a3) : "s23"); asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(a4) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(a5) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(a6) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(a7) : "s23");) }
+        if (OP == 28) { REP8(asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc"); asm volatile("s_add_u32 s21, s21, 1" ::: "s21", "scc"); asm volatile("s_add_u32 s22, s22, 1" ::: "s22", "scc"); asm volatile("s_add_u32 s23, s23, 1" ::: "s23", "scc"); asm volatile("s_and_b64 s[24:25], s[24:25], exec" ::: "s24", "s25", "scc"); asm volatile("s_or_b64 s[26:27], s[26:27], exec" ::: "s26", "s27", "scc"); asm volatile("s_mov_b32 s28, s20" ::: "s28"); asm volatile("s_nop 0");) }
+        if (OP == 29) { REP8(asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d0) : "v"(a0)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a1) : "v"(d1)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d2) : "v"(a2)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a3) : "v"(d3)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d4) : "v"(a4)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a5) : "v"(d5)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d6) : "v"(a6)); asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a7) : "v"(d7));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -89,10 +101,22 @@ template <int OP> double run(int wavesPerSimd, int trips, int per) {
 
 int main() {
     const char *names[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_rcp_f32", "v_sqrt_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_pk_fma_f32", "v_pk_mul_f32",
-                           "v_pk_add_f32", "v_div_fixup_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_max_f32", "v_and_b32", "fma+mul mix", "v_mov_b32"};
+                           "v_pk_add_f32", "v_div_fixup_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_max_f32", "v_and_b32", "fma+mul mix", "v_mov_b32", "v_min_f32", "v_max3_f32", "v_cndmask_b32", "v_cmp_lt_f32", "v_div_fmas_f32", "v_add_u32", "v_mad_u32_u24", "v_mad_u64_u32",
+                           "v_lshl_add_u64", "v_readlane_b32", "SALU mix (8)", "cvt f64<->f32"};
     printf("%-18s %8s %8s %8s   (s_memtime ticks per wave-instruction per SIMD)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD");
 #define ROW(OP, per) printf("%-18s %8.2f %8.2f %8.2f\n", names[OP], run<OP>(1, 2000, per), run<OP>(2, 2000, per), run<OP>(4, 2000, per));
     ROW(0, 64) ROW(1, 64) ROW(2, 64) ROW(3, 64) ROW(4, 64) ROW(5, 64) ROW(6, 64) ROW(7, 64) ROW(8, 64) ROW(9, 64) ROW(10, 64) ROW(11, 64) ROW(12, 64) ROW(13, 64)
-    ROW(14, 64) ROW(15, 64) ROW(16, 128) ROW(17, 64)
+    ROW(14, 64) ROW(15, 64) ROW(16, 128) ROW(17, 64) ROW(18, 64) ROW(19, 64) ROW(20, 64) ROW(21, 64) ROW(22, 64) ROW(23, 64) ROW(24, 64) ROW(25, 64) ROW(26, 64) ROW(27, 64) ROW(28, 64) ROW(29, 64)
+    {   // tick calibration: wall time of a long v_fma run against its ticks
+        int blocks = 256; float *out; unsigned long long *cyc;
+        hipMalloc(&out, sizeof(float) * blocks * 256); hipMalloc(&cyc, 8 * blocks * 4);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, 20000, out, cyc); hipDeviceSynchronize();
+        hipEventRecord(e0, 0); hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, 200000, out, cyc); hipEventRecord(e1, 0); hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(blocks * 4); hipMemcpy(h.data(), cyc, 8 * blocks * 4, hipMemcpyDeviceToHost);
+        double s = 0; for (auto v : h) s += (double)v; s /= h.size();
+        printf("calibration: %.0f s_memtime ticks in %.3f ms of kernel time = %.1f MHz tick rate; v_fma_f32 one wave per SIMD = %.2f ns each\n", s, ms, s / ms / 1e3, ms * 1e6 / (200000.0 * 64));
+    }
     return 0;
 }
