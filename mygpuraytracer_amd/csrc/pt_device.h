@@ -557,6 +557,9 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
 
 // meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space
 // distance, as the reference does.  (intersectionPoint, which the reference also fills, has no reader.)
+// LDSF: the caller knows that the triangle tables are staged in LDS (sc.tri_lds && sc.ntri_lds): every table read is then a
+// ds_read from a pointer the compiler can see is LDS, instead of a run-time choice per word
+template <bool LDSF = false>
 PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, int bvhRoot = -1, int j0 = 0, int j1 = 0x7fffffff,
                           int32_t *stack = nullptr, int stride = 0) {
     Ray q;
@@ -582,7 +585,7 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
     if (j1 > geom.faceCount) j1 = geom.faceCount;
     for (int j = j0; j < j1; j++) {       // (the whole face list unless the caller spreads it over lanes)
         vec3 v0, e1, e2;
-        if (sc.tri_lds && sc.ntri_lds) {      // broadcast ds_reads: every lane reads the same triangle
+        if (LDSF || (sc.tri_lds && sc.ntri_lds)) {      // broadcast ds_reads: every lane reads the same triangle
             const float *t9 = reinterpret_cast<const float *>(pt_lds) + (size_t)(geom.faceStart + j) * 9;
             v0 = V3(t9[0], t9[1], t9[2]); e1 = V3(t9[3], t9[4], t9[5]); e2 = V3(t9[6], t9[7], t9[8]);
         } else {
@@ -592,15 +595,18 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
         float b0, b1;
         if (rayTriangle(q.o, q.d, v0, e1, e2, b0, b1)) {
             const int f = geom.faceStart + j;
-            vec3 p1 = faceVec(sc, f, 5), p2 = faceVec(sc, f, 10);
+            // the face record (3 x pos xyz, uv) of the hit, through ONE pointer (LDS when the caller said so at compile time)
+            const float *F = LDSF ? reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 9 + f * 15
+                                  : ((sc.tri_lds && sc.ntri_lds) ? reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 9 + f * 15 : sc.faces + (size_t)f * 15);
+            vec3 p1 = V3(F[5], F[6], F[7]), p2 = V3(F[10], F[11], F[12]);
             float w = 1 - b0 - b1;
             vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
             float t = length(sub(q.o, p));          // glm::distance(p, q.origin)
             if (t < tmin) {
                 tmin = t;
                 nearest = j;
-                c.u = (w * faceWord(sc, f, 3) + b0 * faceWord(sc, f, 8)) + b1 * faceWord(sc, f, 13);
-                c.v = (w * faceWord(sc, f, 4) + b0 * faceWord(sc, f, 9)) + b1 * faceWord(sc, f, 14);
+                c.u = (w * F[3] + b0 * F[8]) + b1 * F[13];
+                c.v = (w * F[4] + b0 * F[9]) + b1 * F[14];
             }
         }
     }
@@ -838,6 +844,7 @@ PT_DEV unsigned long long primKey(const float *gtab, int g, Ray ray) {
 }
 
 // mesh g against one ray (g may differ per lane: its header is gathered from LDS)
+template <bool LDSF = false>
 PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ray ray, int chunk = -1, int32_t *stack = nullptr,
                                   int stride = 0) {
     const float *G = gtab + g * GTAB_WORDS;
@@ -856,11 +863,11 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
     float t;
     if (chunk >= 0) {
         if (chunk * MESH_CHUNK >= geom.faceCount) return KEY_NONE;
-        t = meshTestCore(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
+        t = meshTestCore<LDSF>(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
     } else {
         // (a stack, when the caller has one and the tree fits it, buys the front-to-back search)
         const bool ordered = stack && sc.bvh_depth && sc.bvh_depth[g] < BVH_STACK;
-        t = meshTestCore(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1, 0, 0x7fffffff, ordered ? stack : nullptr, stride);
+        t = meshTestCore<LDSF>(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1, 0, 0x7fffffff, ordered ? stack : nullptr, stride);
     }
     if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
     return packKey(t, g, (uint32_t)c.face);

@@ -349,7 +349,8 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
                 Ray r;
                 r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
                 r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
-                const unsigned long long key = k < startM ? primKey(gtab, g, r) : meshKey(sc, gtab, g, r, chunk);
+                // (tileIntersect runs with the tables staged; the triangle tables too unless the scene's meshes are too big)
+                const unsigned long long key = k < startM ? primKey(gtab, g, r) : (sc.ntri_lds ? meshKey<true>(sc, gtab, g, r, chunk) : meshKey<false>(sc, gtab, g, r, chunk));
                 if (key != KEY_NONE) atomicMin(&best[src], key);
             }
         }
