@@ -2,10 +2,37 @@
 // `//TODO BVH` src/pathtrace.cu:289, BOUNDING_BOX :40,306-311).  It changes WHICH triangles meshIntersectionTest
 // (src/intersections.h:207-233) looks at, never what it computes for one: every visited triangle goes through the
 // same rayTriangle + barycentric point + distance arithmetic, and the winner is the minimum of (distance, face
-// index) -- the reference's strict `t < tmin` in face order.  A subtree is skipped only when the ray misses its box
-// (inflated well beyond fp32 error) or the box starts behind the best hit so far (with slack), so the result equals
-// the brute-force loop's; tests/test_bvh.py checks that on random and grazing rays (CPU, this header compiled for
-// the host) and tests/test_gpu_parity.py against the oracle's brute force on the GPU.
+// index) -- the reference's strict `t < tmin` in face order.
+//
+// Why the tree equals the loop (a bound, not a sample).  A subtree is skipped in two cases only.
+//  (1) Its box starts beyond the best distance so far.  The best distance is |o - p|, p = w v0 + b0 p1 + b1 p2 with the
+//      ACCEPTED barycentrics 0 <= b0 <= 1, b1 >= 0, b0 + b1 <= 1: a point of the triangle up to one rounding, hence of every
+//      box around it.  A box whose entry parameter exceeds 1.0001 x that distance cannot hold a triangle with a nearer
+//      such point.  No assumption about how well the triangle test is conditioned.
+//  (2) The ray misses its box.  Here the argument needs the rounding error of glm::intersectRayTriangle in binary32.
+//      With u = 2^-24, D = |o - v0|, |d| = 1, the computed quantities satisfy (standard dot / cross product bounds)
+//          |a - a*| <= 6.5 u |e1||e2|,   |s.p - (s.p)*| <= 7.5 u D |e2|,   |d.q - (d.q)*| <= 8 u D |e1|,   |e2.q - (e2.q)*| <= 8 u D |e1||e2|
+//      so when the test accepts (a >= FLT_EPSILON, 0 <= bx <= 1, by >= 0, bx + by <= 1, bz >= 0) the EXACT barycentrics and
+//      ray parameter of the line's intersection with the triangle's plane obey
+//          -eu <= u* <= 1 + eu,  -ev <= v*,  u* + v* <= 1 + eu + ev,  t* >= -et,
+//          eu <= (13 u |e1||e2| + 15 u D |e2|) / a + 4u,   ev <= (13 u |e1||e2| + 16 u D |e1|) / a + 4u,   et <= 16 u D |e1||e2| / a.
+//      The exact intersection point therefore lies within  eu |e1| + ev |e2|  of the triangle, and with the conditioning
+//      kappa = a / (|e1||e2|)  (= sin(angle e1,e2) x |cos(angle ray, normal)|, at most 1)
+//          distance(ray, triangle) + (how far behind the origin)  <=  (31 u D + 26 u L + 16 u D) / kappa + 8 u L  <  64 u (D + L) / kappa,
+//      L = max(|e1|, |e2|) -- the aspect ratio of the triangle cancels, only kappa remains.  So a ray the loop accepts a
+//      triangle for reaches every box around that triangle WIDENED BY 64 u (D + L) / kappa.  The traversal widens every
+//      slab by  slack = 2^11 u (|o - c| + 4 R)  (c, R: centre and half diagonal of the root box; D <= |o - c| + R, L <= 2R;
+//      bvhSlack / slabEntry in pt_device.h), on top of the static inflation below and of the slab test's own rounding
+//      (4 u (|o| + |box|) per plane, inside the 4 R term).  Hence:
+//
+//          for EVERY ray, at ANY distance, the tree returns the loop's face and distance whenever each triangle the loop
+//          accepts is conditioned no worse than kappa >= 2^-5 (about 1.8 degrees off grazing for a right-angled triangle).
+//
+//      Below that conditioning the reference's own test decides by rounding noise over a band of width ~64 u D / kappa along
+//      the triangle's edges; the static inflation (2e-3 of the node's diagonal + 1e-5 of the mesh's) still covers most of
+//      it, but equality there is measured (tests/test_bvh.py: grazing rays, needles, far origins up to 10^6 mesh sizes),
+//      not proven.  The slack grows with distance: a ray from 10^4 mesh sizes away prunes little -- as it must, its
+//      triangle tests being accurate to a fraction of the mesh only.
 //
 // The traversal (bvhNearest) lives in pt_device.h next to the triangle test; this header is the host-side builder.
 // Layout ("threaded" preorder, no stack): node = 2 x 16 bytes {lo.xyz, skip}{hi.xyz, leaf}.  skip = the next node

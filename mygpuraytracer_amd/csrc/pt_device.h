@@ -435,28 +435,55 @@ PT_HD bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &bx
 
 // ---- BVH traversal (builder and layout: pt_bvh.h) ------------------------------------------------------------------
 
-// Nearest face of the mesh whose tree starts at node `root`, object-space ray (o, d normalised as the reference
-// does).  Returns the object-space distance (FLT_MAX: none); face = index inside the geom, b0/b1 = its barycentrics.
-PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restrict__ tris, int root, vec3 o, vec3 d,
-                       int &face, float &b0o, float &b1o, int *visited = nullptr) {
+// The box test of both traversals.  It is not part of the reference's arithmetic -- it only decides which triangles are
+// looked at -- so it is free to be any test that never misses a box the ray reaches WITHIN `slack`: planes through one FMA
+// each, t = plane * (1/d) - o * (1/d), and every slab widened by slack * |1/d| (a distance `slack` along that axis).
+// slack is per ray, bvhSlack() below; why it is what makes the tree equal the loop is derived in pt_bvh.h.
+struct RaySlab { float ix, iy, iz, ox, oy, oz, sx, sy, sz; };
+PT_HD RaySlab makeRaySlab(vec3 o, vec3 d, float slack) {
     const float tiny = 1e-20f;
     const float ddx = __builtin_fabsf(d.x) < tiny ? __builtin_copysignf(tiny, d.x) : d.x;
     const float ddy = __builtin_fabsf(d.y) < tiny ? __builtin_copysignf(tiny, d.y) : d.y;
     const float ddz = __builtin_fabsf(d.z) < tiny ? __builtin_copysignf(tiny, d.z) : d.z;
-    const float ix = 1.0f / ddx, iy = 1.0f / ddy, iz = 1.0f / ddz;
+    RaySlab r;
+    r.ix = 1.0f / ddx; r.iy = 1.0f / ddy; r.iz = 1.0f / ddz;
+    r.ox = o.x * r.ix; r.oy = o.y * r.iy; r.oz = o.z * r.iz;
+    r.sx = slack * __builtin_fabsf(r.ix); r.sy = slack * __builtin_fabsf(r.iy); r.sz = slack * __builtin_fabsf(r.iz);
+    return r;
+}
+// false = skip the subtree: the widened box is missed, lies behind the origin, or starts beyond the best distance so far.
+// (The best distance is the distance to a point INSIDE its triangle, hence inside every box around that triangle, so a box
+// that starts beyond it cannot hold a nearer hit whatever the rounding of the triangle test; 1.0001 covers the rounding
+// of the distance itself.)  Any NaN => visit.
+PT_HD bool slabEntry(const BvhQuad &A, const BvhQuad &B, const RaySlab &r, float tmin, float &tn) {
+    const float x0 = __builtin_fmaf(A.x, r.ix, -r.ox), x1 = __builtin_fmaf(B.x, r.ix, -r.ox);
+    const float y0 = __builtin_fmaf(A.y, r.iy, -r.oy), y1 = __builtin_fmaf(B.y, r.iy, -r.oy);
+    const float z0 = __builtin_fmaf(A.z, r.iz, -r.oz), z1 = __builtin_fmaf(B.z, r.iz, -r.oz);
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1) - r.sx, __builtin_fminf(y0, y1) - r.sy), __builtin_fminf(z0, z1) - r.sz);
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1) + r.sx, __builtin_fmaxf(y0, y1) + r.sy), __builtin_fmaxf(z0, z1) + r.sz);
+    return !((tf < tn) || (tf < 0.0f) || (tn > tmin * 1.0001f));
+}
+// The per-ray slack: 2^11 u (|o - c| + 4 R), u = 2^-24, c and R the centre and half diagonal of the tree's root box
+// (pt_bvh.h, "Why the tree equals the loop").
+PT_HD float bvhSlack(const BvhQuad &A, const BvhQuad &B, vec3 o) {
+    const vec3 c = V3(0.5f * (A.x + B.x), 0.5f * (A.y + B.y), 0.5f * (A.z + B.z));
+    const vec3 h = V3(0.5f * (B.x - A.x), 0.5f * (B.y - A.y), 0.5f * (B.z - A.z));
+    const float s = 1.220703125e-4f * (length(sub(o, c)) + 4.0f * length(h));       // 2^11 * 2^-24 = 2^-13
+    return s == s ? s : 3.0e38f;                       // non-finite inputs: never cull
+}
+
+// Nearest face of the mesh whose tree starts at node `root`, object-space ray (o, d normalised as the reference
+// does).  Returns the object-space distance (FLT_MAX: none); face = index inside the geom, b0/b1 = its barycentrics.
+PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restrict__ tris, int root, vec3 o, vec3 d,
+                       int &face, float &b0o, float &b1o, int *visited = nullptr) {
+    const RaySlab rs = makeRaySlab(o, d, bvhSlack(nodes[2 * root], nodes[2 * root + 1], o));
     float tmin = 3.402823466e+38f;
     face = -1; b0o = 0.f; b1o = 0.f;
     int n = root;
     while (n >= 0) {
         const BvhQuad A = nodes[2 * n], B = nodes[2 * n + 1];
-        const float x0 = (A.x - o.x) * ix, x1 = (B.x - o.x) * ix;
-        const float y0 = (A.y - o.y) * iy, y1 = (B.y - o.y) * iy;
-        const float z0 = (A.z - o.z) * iz, z1 = (B.z - o.z) * iz;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-        // any NaN => visit.  The hit point of a triangle in this box lies on the ray at a parameter >= tn, and its
-        // distance is that parameter up to rounding, so a box that starts beyond the best distance cannot improve it.
-        const bool skip = (tf < tn) || (tf < 0.0f) || (tn > tmin * 1.0001f);
+        float tn_;
+        const bool skip = !slabEntry(A, B, rs, tmin, tn_);
         if (visited) ++*visited;
         if (skip) { n = A.w; continue; }
         const int count = (int)((uint32_t)B.w >> 28), first = B.w & 0x0fffffff;
@@ -487,21 +514,10 @@ PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restric
 // and the same (distance, face index) minimum: same answer.  Needs depth <= cap - 1 (pt_bvh.h records the depth).
 PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__restrict__ tris, int root, vec3 o, vec3 d,
                               int &face, float &b0o, float &b1o, int32_t *stack, int stride, int *visited = nullptr) {
-    const float tiny = 1e-20f;
-    const float ddx = __builtin_fabsf(d.x) < tiny ? __builtin_copysignf(tiny, d.x) : d.x;
-    const float ddy = __builtin_fabsf(d.y) < tiny ? __builtin_copysignf(tiny, d.y) : d.y;
-    const float ddz = __builtin_fabsf(d.z) < tiny ? __builtin_copysignf(tiny, d.z) : d.z;
-    const float ix = 1.0f / ddx, iy = 1.0f / ddy, iz = 1.0f / ddz;
+    const RaySlab rs = makeRaySlab(o, d, bvhSlack(nodes[2 * root], nodes[2 * root + 1], o));
     float tmin = 3.402823466e+38f;
     face = -1; b0o = 0.f; b1o = 0.f;
-    auto entry = [&](const BvhQuad &A, const BvhQuad &B, float &tn) {       // false = skip (same rule as bvhNearest)
-        const float x0 = (A.x - o.x) * ix, x1 = (B.x - o.x) * ix;
-        const float y0 = (A.y - o.y) * iy, y1 = (B.y - o.y) * iy;
-        const float z0 = (A.z - o.z) * iz, z1 = (B.z - o.z) * iz;
-        tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-        return !((tf < tn) || (tf < 0.0f) || (tn > tmin * 1.0001f));
-    };
+    auto entry = [&](const BvhQuad &A, const BvhQuad &B, float &tn) { return slabEntry(A, B, rs, tmin, tn); };       // false = skip
     int sp = 0;
     int n = root;                 // node in hand (its box is tested when it is taken in hand), -1 = pop
     {

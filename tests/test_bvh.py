@@ -139,3 +139,32 @@ def test_needles_tiny_and_far(product):
     rays = np.concatenate([rays, np.concatenate([o, cent - o], axis=1)]).astype(np.float32)
     fl, st = assert_same(run_check(product, faces, rays))
     assert (fl >= 0).sum() > 3000
+
+
+@pytest.mark.parametrize("ratio", [1e3, 1e4, 1e5, 1e6])
+def test_far_origin_sweep(product, ratio):
+    """Origins 10^3 ... 10^6 mesh sizes away (binary32 barycentrics are then accurate to 1e-4 ... 1e-1 of an edge: the loop's
+    own hits and misses are partly rounding noise).  The traversal's per-ray slack grows with the distance (pt_bvh.h, "Why the
+    tree equals the loop"), so the tree still looks at every triangle the loop can accept: zero disagreements, on a
+    well-shaped hull and on a soup with needles."""
+    rng = np.random.default_rng(int(ratio) % 9973)
+    faces = hull(24, 48)                      # 2304 triangles, size ~ 3
+    n = 6000
+    rays = rays_around(rng, n, 3.0 * ratio, 1.6)
+    fl, st = assert_same(run_check(product, faces, rays))
+    assert (fl >= 0).sum() > n // 20
+    m = 800
+    base = rng.uniform(-1, 1, size=(m, 3))
+    tri = np.stack([base, base + rng.normal(size=(m, 3)) * rng.uniform(0.3, 1.5, size=(m, 1)), base + rng.normal(scale=2e-2, size=(m, 3))], axis=1).astype(np.float32)
+    soup = np.concatenate([tri, np.zeros((m, 3, 2), np.float32)], axis=2).reshape(m, 15)
+    assert_same(run_check(product, soup, rays_around(rng, 4000, 2.0 * ratio, 1.0)))
+
+
+def test_near_rays_still_prune(product):
+    """The slack must not cost the tree its point: from ordinary viewing distances (2-4 mesh sizes) a ray still visits a
+    small fraction of a 9216-triangle hull."""
+    rng = np.random.default_rng(23)
+    faces = hull(48, 96)
+    rays = rays_around(rng, 8000, 8.0, 1.5)
+    fl, st = assert_same(run_check(product, faces, rays))
+    assert st[2] / len(rays) < 450
