@@ -203,7 +203,10 @@ struct alignas(16) BvhQuad { float x, y, z; int32_t w; };
 #ifndef PT_MESH_CHUNK
 #define PT_MESH_CHUNK 4
 #endif
-constexpr int MESH_CHUNK = PT_MESH_CHUNK;            // faces per lane when a small mesh's loop is spread over lanes
+constexpr int MESH_CHUNK = PT_MESH_CHUNK;
+#ifndef PT_DEFER_HITS
+#define PT_DEFER_HITS 1       // chunked small meshes: accepted triangles' distances are evaluated after the chunk's tests (meshChunkTestLds)
+#endif            // faces per lane when a small mesh's loop is spread over lanes
 #ifndef PT_BVH_LEAF
 #define PT_BVH_LEAF 2
 #endif
@@ -860,6 +863,50 @@ PT_DEV unsigned long long primKey(const float *gtab, int g, Ray ray) {
 }
 
 // mesh g against one ray (g may differ per lane: its header is gathered from LDS)
+// One chunk of a small mesh (faces [j0, j0 + MESH_CHUNK) of the geom, tables in LDS) for tileIntersect.  Same tests, same
+// comparisons in the same order as the loop of meshTestCore; what differs is WHEN the distance of an accepted triangle is
+// evaluated.  In a wave whose lanes hold different rays some lane hits almost every triangle, so the loop pays for the hit
+// path (two vertices, the barycentric point, a square root) at every triangle for all lanes.  Here the triangle tests run
+// first and only remember hit bits and barycentrics; the hit path then runs once per hit a lane HAS -- in face order, with
+// the loop's strict `t < tmin` -- i.e. about once per chunk instead of MESH_CHUNK times.
+PT_DEV float meshChunkTestLds(const DScene &sc, const float *inv12, int faceStart, int faceCount, int j0, Ray r, int &nearest) {
+    Ray q;
+    q.o = mulRows(inv12, r.o, 1.0f);                 // = multiplyMV(geom.inverseTransform, ., .): same products, same sums
+    q.d = normalize(mulRows(inv12, r.d, 0.0f));
+    const float *L = reinterpret_cast<const float *>(pt_lds);
+    float bx[MESH_CHUNK], by[MESH_CHUNK];
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < MESH_CHUNK; k++) {
+        bx[k] = by[k] = 0.f;
+        const int j = j0 + k;
+        if (j < faceCount) {
+            const float *t9 = L + (size_t)(faceStart + j) * 9;
+            const vec3 v0 = V3(t9[0], t9[1], t9[2]), e1 = V3(t9[3], t9[4], t9[5]), e2 = V3(t9[6], t9[7], t9[8]);
+            float b0, b1;
+            if (rayTriangle(q.o, q.d, v0, e1, e2, b0, b1)) { hits |= 1u << k; bx[k] = b0; by[k] = b1; }
+        }
+    }
+    float tmin = 3.402823466e+38f;
+    nearest = -1;
+    while (hits) {                                   // increasing face index, as the loop visits them
+        const int k = __ffs((int)hits) - 1;
+        hits &= hits - 1;
+        float b0 = bx[0], b1 = by[0];
+#pragma unroll
+        for (int m = 1; m < MESH_CHUNK; m++) { b0 = k == m ? bx[m] : b0; b1 = k == m ? by[m] : b1; }
+        const int f = faceStart + j0 + k;
+        const float *t9 = L + (size_t)f * 9;
+        const float *F = L + sc.ntri_lds * 9 + f * 15;
+        const vec3 v0 = V3(t9[0], t9[1], t9[2]), p1 = V3(F[5], F[6], F[7]), p2 = V3(F[10], F[11], F[12]);
+        const float w = 1 - b0 - b1;
+        const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
+        const float t = length(sub(q.o, p));          // glm::distance(p, q.origin)
+        if (t < tmin) { tmin = t; nearest = j0 + k; }
+    }
+    return nearest == -1 ? -1.f : tmin;
+}
+
 template <bool LDSF = false>
 PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ray ray, int chunk = -1, int32_t *stack = nullptr,
                                   int stride = 0) {
@@ -879,7 +926,15 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
     float t;
     if (chunk >= 0) {
         if (chunk * MESH_CHUNK >= geom.faceCount) return KEY_NONE;
-        t = meshTestCore<LDSF>(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
+        if (LDSF && PT_DEFER_HITS) {
+            float inv[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) inv[k] = G[k];
+            int nearest;
+            t = meshChunkTestLds(sc, inv, geom.faceStart, geom.faceCount, chunk * MESH_CHUNK, ray, nearest);
+            c.face = nearest;
+        } else
+            t = meshTestCore<LDSF>(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
     } else {
         // (a stack, when the caller has one and the tree fits it, buys the front-to-back search)
         const bool ordered = stack && sc.bvh_depth && sc.bvh_depth[g] < BVH_STACK;
