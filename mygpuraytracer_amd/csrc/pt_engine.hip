@@ -163,7 +163,9 @@ struct BounceParams {
     DScene sc;
     DCamera cam;
     TileMap tm;
-    PathSoA in, stage;
+    PathSoA in, stage;                     // in = the stage the previous bounce wrote (tile order), read through perm_*
+    const int32_t *perm_src, *perm_idx;    // sorted position -> slot of `in` / RNG stream index (what k_move wrote)
+    size_t seg_perm;                       // per-segment stride of perm_* (0: the cached bounce-0 permutation, shared)
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
@@ -439,12 +441,15 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     InRec nxt;
     auto fetch = [&](int tile_, InRec &r) {
         const PathSoA in = soa_fresh(in_k);
-        const int j = min(tile_ * TILE + tid, n_in - 1);
+        const int jp = min(tile_ * TILE + tid, n_in - 1);
+        // the sorted stream is not materialised: position jp of it is slot j of the previous bounce's stage
+        const int j = (p.perm_src + p.seg_perm * seg)[jp];
+        r.idx = (p.perm_idx + p.seg_perm * seg)[jp];
 #pragma unroll
         for (int k = 0; k < 12; k++) r.f[k] = in.field(k)[j];
         r.f[12] = r.f[13] = 0.f;
         if (p.uses_uv) { r.f[12] = in.u()[j]; r.f[13] = in.v()[j]; }
-        r.pix = in.pix()[j]; r.mg = in.mg()[j]; r.idx = in.idx()[j];
+        r.pix = in.pix()[j]; r.mg = in.mg()[j];
     };
     if (PIPE && tile0 < tile1) fetch(tile0, nxt);
     for (int tile = tile0; tile < tile1; tile++) {
@@ -739,20 +744,26 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p)
 }
 
 struct MoveParams {
-    PathSoA stage, out;
-    int32_t nbins, maxTiles, first, owned, nsuper, uses_uv;
+    PathSoA stage;
+    int32_t *perm_src, *perm_idx;          // out: for every sorted position, the stage slot of its path and its RNG stream index
+    int32_t nbins, maxTiles, first, owned, nsuper;
     const int32_t *totals_prev;
     const int32_t *counts_all, *counts_scat, *chunk_all, *chunk_scat, *super_all, *super_scat, *totals_all, *totals_scat;
-    size_t seg_stage, seg_out, seg_counts, seg_chunk, seg_totals;      // per-segment strides, as in BounceParams
+    size_t seg_stage, seg_perm, seg_counts, seg_chunk, seg_totals;      // per-segment strides, as in BounceParams
 };
 
-// Stable multi-bin partition: stored path -> position binBase[bin] + chunkBase[bin] + prefixInChunk + rankInTile.
+// Stable multi-bin partition, as an INDEX: stored path -> position binBase[bin] + chunkBase[bin] + prefixInChunk + rankInTile;
+// what is written there is not the 60-byte record but where it lies (its stage slot) and the stream index that seeds its RNG.
+// The next k_bounce gathers its records through that index.  Stage tiles are sorted by bin, and the partition is stable,
+// so consecutive positions of one bin are consecutive slots of one tile's run, then of the next tile's: the gather reads
+// runs, not scattered words.  (The records themselves move once per bounce -- out of k_bounce -- instead of twice.)
 // Must be launched with the same grid as the k_bounce that produced the counts (same chunking of tiles).
 __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
     const int nb = p.nbins, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *base_all = pt_lds, *base_scat = pt_lds + nb;          // dynamic LDS: base_all[nb], base_scat[nb]
     const int seg = blockIdx.y;
-    const PathSoA stage_k = soa_offset(p.stage, p.seg_stage * seg), out_k = soa_offset(p.out, p.seg_out * seg);
+    const PathSoA stage_k = soa_offset(p.stage, p.seg_stage * seg);
+    int32_t *perm_src = p.perm_src + p.seg_perm * seg, *perm_idx = p.perm_idx + p.seg_perm * seg;
     const int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
     const int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
     const int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
@@ -778,35 +789,18 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
         if (lane == 0) (which ? base_scat : base_all)[b] = s;
     }
     __syncthreads();
-    // MOVE_U tiles per step: all loads of a step are issued before the first store, which is what hides the HBM
-    // latency here (one tile's 15 loads per lane in flight is not enough at 8 waves per SIMD)
+    // MOVE_U tiles per step: their keys are requested before the first is used
 #ifndef PT_MOVE_U
-#define PT_MOVE_U 6
+#define PT_MOVE_U 4
 #endif
     constexpr int MOVE_U = PT_MOVE_U;
+    const int32_t *keys = stage_k.idx();
     for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
-        const PathSoA stage = soa_fresh(stage_k), out = soa_fresh(out_k);
-        size_t i[MOVE_U];
         int32_t key[MOVE_U];
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
             const int tile = tbase + u;
-            i[u] = (size_t)min(tile, tile1 - 1) * TILE + tid;
-            key[u] = stage.idx()[i[u]];
-            if (tile >= tile1) key[u] = -1;
-        }
-        float f[MOVE_U][14];
-        int32_t pixv[MOVE_U], mgv[MOVE_U];
-#pragma unroll
-        for (int u = 0; u < MOVE_U; u++) {
-            if (key[u] != -1) {
-                f[u][0] = stage.px()[i[u]]; f[u][1] = stage.py()[i[u]]; f[u][2] = stage.pz()[i[u]];
-                f[u][3] = stage.dx()[i[u]]; f[u][4] = stage.dy()[i[u]]; f[u][5] = stage.dz()[i[u]];
-                f[u][6] = stage.cr()[i[u]]; f[u][7] = stage.cg()[i[u]]; f[u][8] = stage.cb()[i[u]];
-                f[u][9] = stage.nx()[i[u]]; f[u][10] = stage.ny()[i[u]]; f[u][11] = stage.nz()[i[u]];
-                if (p.uses_uv) { f[u][12] = stage.u()[i[u]]; f[u][13] = stage.v()[i[u]]; }
-                pixv[u] = stage.pix()[i[u]]; mgv[u] = stage.mg()[i[u]];
-            }
+            key[u] = tile < tile1 ? keys[(size_t)tile * TILE + tid] : -1;
         }
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
@@ -815,15 +809,19 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
             const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
             const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + r_all;
             const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + r_scat;
-            out.px()[pos] = f[u][0]; out.py()[pos] = f[u][1]; out.pz()[pos] = f[u][2];
-            out.dx()[pos] = f[u][3]; out.dy()[pos] = f[u][4]; out.dz()[pos] = f[u][5];
-            out.cr()[pos] = f[u][6]; out.cg()[pos] = f[u][7]; out.cb()[pos] = f[u][8];
-            out.nx()[pos] = f[u][9]; out.ny()[pos] = f[u][10]; out.nz()[pos] = f[u][11];
-            if (p.uses_uv) { out.u()[pos] = f[u][12]; out.v()[pos] = f[u][13]; }
-            out.pix()[pos] = pixv[u];
-            out.mg()[pos] = mgv[u];
-            out.idx()[pos] = idx;
+            perm_src[pos] = tile * TILE + tid;
+            perm_idx[pos] = idx;
         }
+    }
+}
+
+// debug capture: the sorted stream materialised (what k_move used to write), position k <- stage slot perm_src[k]
+__global__ void k_capture(PathSoA stage, const int32_t *perm_src, const int32_t *perm_idx, int cap, int32_t *out_i, float *out_f) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += gridDim.x * blockDim.x) {
+        int j = perm_src[k];
+        j = j < 0 ? 0 : (j >= cap ? cap - 1 : j);               // positions past the stream's end hold whatever was there before
+        out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = perm_idx[k]; out_i[2 * (size_t)cap + k] = stage.mg()[j];
+        for (int f = 0; f < SOA_FLOATS; f++) out_f[(size_t)f * cap + k] = stage.field(f)[j];
     }
 }
 
@@ -1019,7 +1017,9 @@ struct ptx_tracer {
     float *d_image = nullptr; bool own_image = false;
     float *d_fbuf[3] = {nullptr, nullptr, nullptr};      // stream, stage, cache
     int32_t *d_ibuf[3] = {nullptr, nullptr, nullptr};
-    PathSoA soa[3];                                      // 0 = stream, 1 = stage, 2 = first-bounce cache
+    PathSoA soa[3];                                      // 0, 1 = the two stages (bounce b writes soa[1 - (b & 1)], b + 1 reads it), 2 = first-bounce cache
+    int32_t *d_perm = nullptr;                           // [2][segments x cap]: sorted position -> stage slot, RNG stream index (k_move)
+    int32_t *d_cache_perm = nullptr;                     // [2][cap]: the same for the cached bounce 0
     int32_t *d_counts = nullptr;                         // [2][nbins][maxTiles]
     int32_t *d_chunk = nullptr;                          // [2][nbins][grid]
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
@@ -1155,6 +1155,7 @@ int free_tracer(ptx_tracer *t) {
     hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
+    hipFree(t->d_perm); hipFree(t->d_cache_perm);
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
     hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps); hipFree(t->d_pbo); hipFree(t->d_denoised);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
@@ -1244,9 +1245,14 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         BounceParams bp;
         bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->split_mesh ? 0 : t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
         // (split: the mesh search runs in k_mesh from global memory, so the triangle tables need no LDS)
-        const bool from_cache = (b == 1 && cache_on);           // with the cache on, bounce 0 always lands in soa[2]
-        bp.in = from_cache ? t->soa[2] : soa_shift(t->soa[0], seg0 * t->cap);
-        bp.stage = soa_shift(t->soa[1], seg0 * t->cap);
+        // bounce b writes its stage into soa[1 - (b & 1)] (bounce 0 of a cache-enabled tracer: into soa[2], kept across
+        // iterations) and reads the previous bounce's through the permutation k_move left
+        const bool from_cache = (b == 1 && cache_on), to_cache = (first && cache_on);
+        bp.in = from_cache ? t->soa[2] : soa_shift(t->soa[b & 1], seg0 * t->cap);
+        bp.stage = to_cache ? t->soa[2] : soa_shift(t->soa[1 - (b & 1)], seg0 * t->cap);
+        bp.perm_src = from_cache ? t->d_cache_perm : t->d_perm + seg0 * t->cap;
+        bp.perm_idx = from_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride + seg0 * t->cap;
+        bp.seg_perm = from_cache ? 0 : (size_t)t->cap;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
         bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
@@ -1257,7 +1263,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.super_all = supers(b, 0); bp.super_scat = supers(b, 1);
         bp.totals_all = totals(b, 0); bp.totals_scat = totals(b, 1);
         bp.nsuper = t->nsuper;
-        bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = (size_t)t->cap;
+        bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = to_cache ? 0 : (size_t)t->cap;
         bp.seg_counts = seg_counts; bp.seg_chunk = seg_chunk; bp.seg_totals = seg_totals;
         bp.stamps = t->d_stamps;
         bp.seg_part = t->seg_part;
@@ -1286,16 +1292,16 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
 
         if (b + 1 < t->traceDepth) {
             MoveParams mp;
-            mp.stage = soa_shift(t->soa[1], seg0 * t->cap);
-            const bool to_cache = (first && cache_on);
-            mp.out = to_cache ? t->soa[2] : soa_shift(t->soa[0], seg0 * t->cap);
-            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper; mp.uses_uv = t->uses_uv;
+            mp.stage = bp.stage;
+            mp.perm_src = to_cache ? t->d_cache_perm : t->d_perm + seg0 * t->cap;
+            mp.perm_idx = to_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride + seg0 * t->cap;
+            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper;
             mp.totals_prev = bp.totals_prev;
             mp.counts_all = counts_all; mp.counts_scat = counts_scat;
             mp.chunk_all = chunk_all; mp.chunk_scat = chunk_scat;
             mp.super_all = supers(b, 0); mp.super_scat = supers(b, 1);
             mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
-            mp.seg_stage = (size_t)t->cap; mp.seg_out = to_cache ? 0 : (size_t)t->cap;
+            mp.seg_stage = bp.seg_stage; mp.seg_perm = to_cache ? 0 : (size_t)t->cap;
             mp.seg_counts = seg_counts; mp.seg_chunk = seg_chunk; mp.seg_totals = seg_totals;
             KT(3, hipLaunchKernelGGL(k_move, dim3(gx, K), dim3(TILE), lds_move, stream, mp));
         }
@@ -1304,15 +1310,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             t->cache_valid = true;
         }
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
-            const PathSoA &src = (first && cache_on) ? t->soa[2] : t->soa[0];
-            size_t cb = sizeof(int32_t) * (size_t)t->cap;
-            HIPCHECK(hipMemcpyAsync(t->d_cap, src.pix(), cb, hipMemcpyDeviceToDevice, stream));
-            HIPCHECK(hipMemcpyAsync(t->d_cap + t->cap, src.idx(), cb, hipMemcpyDeviceToDevice, stream));
-            HIPCHECK(hipMemcpyAsync(t->d_cap + 2 * (size_t)t->cap, src.mg(), cb, hipMemcpyDeviceToDevice, stream));
+            // (K == 1, lane 0: segment 0 of the buffers)
+            hipLaunchKernelGGL(k_capture, dim3(std::min(1024, (t->cap + 255) / 256)), dim3(256), 0, stream, bp.stage,
+                               to_cache ? t->d_cache_perm : t->d_perm, to_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride,
+                               t->cap, t->d_cap, t->d_cap_f);
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
-            for (int f = 0; f < SOA_FLOATS; f++)
-                HIPCHECK(hipMemcpyAsync(t->d_cap_f + (size_t)f * t->cap, src.field(f),
-                                        sizeof(float) * (size_t)t->cap, hipMemcpyDeviceToDevice, stream));
             t->cap_filled = true;
         }
     }
@@ -1683,6 +1685,12 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMalloc(&t->d_fbuf[k], sizeof(float) * SOA_FLOATS * stride));
         HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
+    }
+    HC(hipMalloc(&t->d_perm, sizeof(int32_t) * 2 * t->field_stride));
+    HC(hipMemset(t->d_perm, 0, sizeof(int32_t) * 2 * t->field_stride));
+    if (t->cache_active()) {
+        HC(hipMalloc(&t->d_cache_perm, sizeof(int32_t) * 2 * (size_t)t->cap));
+        HC(hipMemset(t->d_cache_perm, 0, sizeof(int32_t) * 2 * (size_t)t->cap));
     }
     t->seg_part = 3 * (size_t)t->cap;                 // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles
     if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * t->seg_part * nseg));
