@@ -13,14 +13,15 @@
 //                 dropped -- only paths that will scatter again are stored.
 //                 Every workgroup owns a contiguous chunk of tiles and keeps running per-material counts, so a
 //                 tile's prefix = (totals of earlier workgroups) + (running count inside the chunk): no scan pass.
-//      k_move   : writes every stored path to its rank in (material descending, previous order) order.  That
-//                 single stable counting sort equals the reference's stable_partition [:541] followed by the
-//                 next bounce's stable sort_by_key by material [:518].  The rank a path WOULD have among all
-//                 survivors (including the ones that were dropped) is carried as its stream index, because
-//                 that index seeds the shading RNG [:373] and must be the reference's.
+//      k_move   : the stable multi-bin partition AS AN INDEX: for every stored path its rank in (material descending,
+//                 previous order) order -- which is the reference's stable_partition [:541] followed by the next bounce's
+//                 stable sort_by_key by material [:518] -- and at that rank the stage slot the path lies in plus the rank
+//                 it WOULD have among all survivors (including the ones that were dropped): that one seeds the shading
+//                 RNG [:373] and must be the reference's.  The 60-byte records stay where k_bounce put them; the next
+//                 k_bounce gathers them through the index (stage tiles are sorted by bin, so it reads runs).
 //  * The live count never visits the host: kernels read it from device memory and use grid-stride tile loops,
 //    so a batch of iterations is a fixed sequence of launches; K iterations ride in every launch as segments
-//    (blockIdx.y), and two such batches are in flight on two streams so that k_move (HBM) overlaps k_bounce (VALU).
+//    (blockIdx.y), and three such batches are in flight on three streams so that their kernels fill each other's tails.
 //  * Intersection is tile-cooperative (tileIntersect): candidate masks from conservative world boxes, the (ray, geom)
 //    pairs of a 256-path tile pooled in LDS and worked off by dense waves with a 64-bit LDS minimum per ray.  Scenes
 //    with BVH meshes run the mesh search as a kernel of its own (k_mesh) between two halves of k_bounce.
