@@ -23,6 +23,7 @@
 #ifndef MI355X_PATHTRACER_H
 #define MI355X_PATHTRACER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
