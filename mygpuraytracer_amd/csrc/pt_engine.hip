@@ -203,9 +203,9 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 // A path that ends adds its radiance to its pixel (finalGather, src/pathtrace.cu:407-416).  Each pixel ends exactly
 // once per iteration, so this is a plain read-modify-write, or -- when several iterations are in flight as
 // segments of one launch -- a plain store into that iteration's buffer.
-__device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, int pix, vec3 c, int apps) {
+__device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, bool batched, int pix, vec3 c, int apps) {
     if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
-    if (part) {
+    if (batched) {
         float *px = part + (size_t)pix * 3;
         px[0] = c.x; px[1] = c.y; px[2] = c.z;
     } else {
@@ -391,8 +391,18 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // tile slot, the key in `keys`) plus one queue entry per (ray, mesh) candidate; k_mesh walks the queue with one lane
 // per entry in dense, lean waves and folds its keys in with 64-bit atomic minima; MODE 2 picks the rays up again and
 // does the rest (winner's normal, terminal cases, ranking, in-tile sort, stage write).  Same arithmetic, same bits.
-template <bool FIRST, int MODE>
-__global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p) {
+// FAST: the options that are run-time values in the general kernel are compile-time constants for the common case -- no
+// textures, no apps variant, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
+// of field, batched radiance buffers, not the cache-filling pass -- so that every test of them, and the code behind the
+// untaken side, is gone (C4: k_bounce -6 %, the first bounce -11 %, fewer registers).  The host picks the variant per launch
+// (enqueue_batch); everything else takes the general kernel, same results.
+template <bool FIRST, int MODE, bool FAST = false>
+__global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p_in) {
+    BounceParams p = p_in;
+    if (FAST) {
+        p.uses_uv = 0; p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
+        p.sc.cull = 1; p.sc.tri_lds = 1; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
+    }
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -420,7 +430,8 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
     int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
     int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
-    float *part = p.part ? p.part + p.seg_part * seg : nullptr;
+    float *part = (FAST || p.part) ? p.part + p.seg_part * seg : nullptr;
+    const bool batched = FAST || part != nullptr;
     const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev + p.seg_totals * seg, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
     // every workgroup owns a contiguous chunk of tiles, so that the prefix of a tile is (prefix of its chunk) +
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 Rng rng; rng.seed(iter, sidx, 0);
                 bool ended = scatterRay(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
-                    deposit(p.tm, p.image, part, pix, ps.color, p.apps);
+                    deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps);
                     alive = false;
                 }
             }
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
                     lit = true;
                     vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-                    deposit(p.tm, p.image, part, pix, c, p.apps);
+                    deposit(p.tm, p.image, part, batched, pix, c, p.apps);
                     if (FIRST && p.emit_count) {
                         const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
                         int k = atomicAdd(p.emit_count, 1);
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             }
             // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
             // in batched mode the path's slot of the per-iteration buffer must still be written
-            if (part && !pending && !lit) {
+            if (batched && !pending && !lit) {
                 float *px = part + (size_t)pix * 3;
                 float z = 0.f;
                 asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
@@ -1033,6 +1044,7 @@ struct ptx_tracer {
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
     uint32_t bump_bits = 0;
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
+    bool no_fast = false;                                // PTX_DEBUG_NO_FAST: always the general k_bounce (A/B timing, tests of both variants)
     unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
     size_t seg_items = 0;
     int cull = 0;
@@ -1287,8 +1299,17 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0;
-            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            else KT(1, hipLaunchKernelGGL((k_bounce<false, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            // the specialised kernel where its assumptions hold (see k_bounce)
+            const bool fast = !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo &&
+                              !bp.emit_count && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
+                              !t->d_bvh_root;
+            if (first) {
+                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            } else {
+                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(1, hipLaunchKernelGGL((k_bounce<false, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            }
         }
 
         if (b + 1 < t->traceDepth) {
@@ -1668,6 +1689,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // iteration); also with one iteration per launch set, i.e. frames so large that only one fits the memory rule above
     // (7680 x 4320: 6.2 -> 4.75 ms per iteration); needs the per-iteration radiance buffers
     t->lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
+    t->no_fast = getenv("PTX_DEBUG_NO_FAST") != nullptr;
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
