@@ -298,7 +298,8 @@ def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product):
 
 def test_tuning_knobs_do_not_change_results(gpu_product, O, monkeypatch):
     """The environment knobs of the library only choose between equivalent execution plans: split mesh search forced on a
-    scene whose mesh has no BVH (k_mesh then runs the plain loop), small-mesh loops not spread over lanes, another grid."""
+    scene whose mesh has no BVH (k_mesh then runs the plain loop), small-mesh loops not spread over lanes, another grid, the
+    general bounce kernel instead of the one specialised for the common option set (k_bounce<.., FAST>)."""
     s, T = make_pair(gpu_product, O, "cornellObj.txt", (160, 90), 8)
     for it in (1, 2, 3):
         O.iterate(it)
@@ -306,7 +307,7 @@ def test_tuning_knobs_do_not_change_results(gpu_product, O, monkeypatch):
     T.render(1, 3)
     assert beq(T.read_image(), want)
     T.close()
-    for var, val in (("PTX_DEBUG_FORCE_SPLIT", "1"), ("PTX_DEBUG_NO_CHUNKS", "1"), ("PTX_DEBUG_WG_PER_CU", "3")):
+    for var, val in (("PTX_DEBUG_FORCE_SPLIT", "1"), ("PTX_DEBUG_NO_CHUNKS", "1"), ("PTX_DEBUG_WG_PER_CU", "3"), ("PTX_DEBUG_NO_FAST", "1")):
         monkeypatch.setenv(var, val)
         with gpu_product.Tracer(s) as T2:
             T2.render(1, 3)
@@ -1146,3 +1147,20 @@ def test_cpp_veneer_on_several_devices(gpu_product, O, tmp_path):
         pbo = T0.pbo(N)
         T0.h = None
     assert np.array_equal(np.frombuffer(open(str(tmp_path / "v") + ".pbo", "rb").read(), np.uint8).reshape(-1, 4), pbo)
+
+
+@pytest.mark.parametrize("scene,res,depth,opt", [("cornellObj.txt", (1920, 1080), 8, {}), ("cornellGlass.txt", (640, 360), 12, {}),
+                                                 ("cornell.txt", (400, 400), 8, dict(antialiasing=0)), ("cornellObj.txt", (320, 200), 8, dict(tile_rows=8, tile_rank=1, tile_world=3))])
+def test_specialised_and_general_bounce_kernels_agree(gpu_product, monkeypatch, scene, res, depth, opt):
+    """k_bounce<.., FAST> (options as compile-time constants, chosen per launch where its assumptions hold) against the general
+    kernel on the same iterations: same image, same ray counts -- at the bench's full size, with the first-bounce cache (whose
+    filling pass is general, whose later passes are specialised) and on a row tile."""
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=depth)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s, **opt) as A:
+        A.render(1, 5)
+        img, st = A.read_image(), A.stats()
+    monkeypatch.setenv("PTX_DEBUG_NO_FAST", "1")
+    with gpu_product.Tracer(s, **opt) as B:
+        B.render(1, 5)
+        assert beq(B.read_image(), img) and B.stats()["rays_total"] == st["rays_total"]
