@@ -395,11 +395,15 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // textures, no apps variant, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
 // of field, batched radiance buffers, not the cache-filling pass -- so that every test of them, and the code behind the
 // untaken side, is gone (C4: k_bounce -6 %, the first bounce -11 %, fewer registers).  The host picks the variant per launch
-// (enqueue_batch); everything else takes the general kernel, same results.
+// (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
+// FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
 __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p_in) {
     BounceParams p = p_in;
-    if (FAST) {
+    if (FAST && MODE != 0) {             // the two halves of the split bounce: the subset that holds for textured BVH scenes too
+        p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
+    }
+    if (FAST && MODE == 0) {
         p.uses_uv = 0; p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
         p.sc.cull = 1; p.sc.tri_lds = 1; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
     }
@@ -1288,15 +1292,26 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
             bp.item_count = t->d_item_count + seg0;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
-            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            else KT(1, hipLaunchKernelGGL((k_bounce<false, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            const bool fast = !t->no_fast && batched && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo && !bp.emit_count;
+            if (first) {
+                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 1, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(0, hipLaunchKernelGGL((k_bounce<true, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            } else {
+                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 1, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(1, hipLaunchKernelGGL((k_bounce<false, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            }
             MeshParams mq;
             mq.sc = t->scene();                                   // tables in global memory
             mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
             mq.seg_stage = bp.seg_stage; mq.seg_keys = bp.seg_keys; mq.seg_items = bp.seg_items;
             KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), sizeof(int32_t) * BVH_STACK * 256, stream, mq));
-            if (first) KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            if (first) {
+                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            } else {
+                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+                else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
+            }
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0;
             // the specialised kernel where its assumptions hold (see k_bounce)
