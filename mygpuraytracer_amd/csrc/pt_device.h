@@ -766,6 +766,11 @@ PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
     const float ddy = __builtin_fabsf(ray.d.y) < tiny ? __builtin_copysignf(tiny, ray.d.y) : ray.d.y;
     const float ddz = __builtin_fabsf(ray.d.z) < tiny ? __builtin_copysignf(tiny, ray.d.z) : ray.d.z;
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
+    // This pre-test is not the reference's arithmetic (it only has to be conservative, and the boxes are inflated by 1e-3 +
+    // 1e-4 |coordinate|, four orders of magnitude beyond its rounding), so each plane costs ONE fused multiply-add,
+    // t = plane * (1/d) - o * (1/d), instead of a subtraction and a multiplication: a quarter fewer instructions for the
+    // stage that every ray runs against every geom.
+    const float ox = -(ray.o.x * ix), oy = -(ray.o.y * iy), oz = -(ray.o.z * iz);
     uint32_t mask = 0;
     const int n = sc.ngeoms;
     for (int i = 0; i < n; i += 2) {
@@ -775,9 +780,9 @@ PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
         for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[j * 8 + k]; }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const float x0 = (bx[h][0] - ray.o.x) * ix, x1 = (bx[h][4] - ray.o.x) * ix;
-            const float y0 = (bx[h][1] - ray.o.y) * iy, y1 = (bx[h][5] - ray.o.y) * iy;
-            const float z0 = (bx[h][2] - ray.o.z) * iz, z1 = (bx[h][6] - ray.o.z) * iz;
+            const float x0 = __builtin_fmaf(bx[h][0], ix, ox), x1 = __builtin_fmaf(bx[h][4], ix, ox);
+            const float y0 = __builtin_fmaf(bx[h][1], iy, oy), y1 = __builtin_fmaf(bx[h][5], iy, oy);
+            const float z0 = __builtin_fmaf(bx[h][2], iz, oz), z1 = __builtin_fmaf(bx[h][6], iz, oz);
             const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
             const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
             const bool culled = (tf < tn) || (tf < 0.0f);      // any NaN => not culled
