@@ -173,6 +173,7 @@ struct BounceParams {
     // split mesh search (MODE 1 / 2 of k_bounce, k_mesh in between): per-ray keys, the queue of (ray, mesh) pairs
     unsigned long long *keys; uint32_t *items; int32_t *item_count;
     size_t seg_keys, seg_items;            // per-segment strides of keys / items; item_count has one int per segment
+    int32_t *tile_done;                    // split first bounce: [segment][tile] 1 = pass 1 finished the tile (no ray of it reaches a mesh's box)
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
@@ -371,8 +372,8 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 constexpr int SPLIT_MAX_MESHES = 2;                  // meshes per scene the split mesh search handles (2 bits of count per ray)
-constexpr int QCAP = 4 * TILE;                       // LDS queue entries (fits rec[12*TILE .. 17*TILE) with its two counters)
-static_assert(12 * TILE + QCAP + 2 <= 17 * TILE, "LDS queue must fit the record buffer");
+constexpr int QCAP = 4 * TILE;                       // LDS queue entries of MODE 1, behind the record buffer, + its two counters
+constexpr int QUEUE_WORDS = QCAP + 4;
 // MODE 1: LDS queue -> global queue of the segment (all threads of the workgroup; uniform call)
 __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const uint32_t *qbuf, int32_t *qcnt, int32_t *qbase, int tid) {
     const int n = *qcnt;
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
-    uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + 12 * TILE);   // MODE 1: LDS stage of the (ray, mesh) queue, [QCAP]
-    int32_t *qcnt = rec + 12 * TILE + QCAP, *qbase = qcnt + 1;
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + REC_WORDS);   // MODE 1: LDS stage of the (ray, mesh) queue, [QCAP], kept
+    int32_t *qcnt = rec + REC_WORDS + QCAP, *qbase = qcnt + 1;        // across tiles (so not inside the record buffer)
     if (MODE == 1 && tid == 0) *qcnt = 0;
     if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
@@ -482,6 +483,19 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
+        if (MODE == 2 && FIRST && p.tile_done && (p.tile_done + (size_t)p.maxTiles * seg)[tile]) {
+            // pass 1 finished this tile (records and keys are in the stage): only its per-bin counts, which pass 1 left in
+            // the prefix tables, are folded into this workgroup's running prefix
+            for (int b = tid; b < nb; b += TILE) {
+                const int ca = counts_all[(size_t)b * p.maxTiles + tile], cs = counts_scat[(size_t)b * p.maxTiles + tile];
+                counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
+                counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+                run_all[b] += ca;
+                run_scat[b] += cs;
+            }
+            __syncthreads();
+            continue;
+        }
         if (MODE == 2) {                 // parked by MODE 1 in this tile's stage slots
             alive = false;
             if (i < n_in) {
@@ -536,6 +550,20 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             if (MODE == 1) {
                 tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
                 if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
+                // Camera rays are coherent: most tiles of the first bounce (256 neighbouring pixels of a row) hold no ray that
+                // reaches a mesh's box at all.  Such a tile is finished right here -- winner's normal, terminal cases,
+                // ranking, in-tile sort, stage write, as in the unsplit kernel -- instead of being parked and picked up again;
+                // its per-bin counts go into the prefix tables as they are, pass 2 folds them into its running prefix.
+                bool finish_here = false;
+                if (FIRST && p.tile_done) {
+                    finish_here = !__syncthreads_or(mesh_cand != 0u);
+                    if (tid == 0) (p.tile_done + (size_t)p.maxTiles * seg)[tile] = finish_here ? 1 : 0;
+                }
+                if (finish_here) {
+                    if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
+                                         p.uses_uv != 0, hit);
+                    goto classify;
+                }
                 // park the ray and queue its mesh candidates: per mesh present in the wave one atomic for the base
                 if (i < n_in) {
                     stage.px()[i] = ray.o.x; stage.py()[i] = ray.o.y; stage.pz()[i] = ray.o.z;
@@ -575,6 +603,7 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
         }
         STAMP(1);        // intersect
         if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
+    classify:
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
             if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)slot_to_pixel(p.tm, pix) * 3);
@@ -644,8 +673,9 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 int ca = 0, cs = 0;
                 if (ln < nb) {
                     for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + ln]; cs += w_scat[w * nb + ln]; }
-                    counts_all[(size_t)ln * p.maxTiles + tile] = run_all[ln];
-                    counts_scat[(size_t)ln * p.maxTiles + tile] = run_scat[ln];
+                    // (MODE 1 finishing a tile: the tile's own counts, for pass 2 to fold in)
+                    counts_all[(size_t)ln * p.maxTiles + tile] = MODE == 1 ? ca : run_all[ln];
+                    counts_scat[(size_t)ln * p.maxTiles + tile] = MODE == 1 ? cs : run_scat[ln];
                     run_all[ln] += ca;
                     run_scat[ln] += cs;
                 }
@@ -664,8 +694,8 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
             for (int b = tid; b < nb; b += TILE) {
                 int ca = 0, cs = 0;
                 for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
-                counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
-                counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+                counts_all[(size_t)b * p.maxTiles + tile] = MODE == 1 ? ca : run_all[b];
+                counts_scat[(size_t)b * p.maxTiles + tile] = MODE == 1 ? cs : run_scat[b];
                 run_all[b] += ca;
                 run_scat[b] += cs;
                 tcs[b] = cs;
@@ -1050,6 +1080,7 @@ struct ptx_tracer {
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
     bool no_fast = false;                                // PTX_DEBUG_NO_FAST: always the general k_bounce (A/B timing, tests of both variants)
     unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
+    int32_t *d_tile_done = nullptr;                      // split first bounce: [segments][maxTiles], see BounceParams::tile_done
     size_t seg_items = 0;
     int cull = 0;
     int nsuper = 1, ntri = 0, tri_lds = 0;
@@ -1169,7 +1200,7 @@ int free_tracer(ptx_tracer *t) {
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamSynchronize(t->lane_stream[l]);      // work traced ahead
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_perm); hipFree(t->d_cache_perm);
@@ -1201,7 +1232,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const int nb = t->nbins;
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
     const int triWords = t->tri_lds ? sceneTableWords(ntri_lds, t->nmats, t->ngeoms) : 0;
-    const size_t lds_bounce = sizeof(int32_t) * bounceLdsWords(triWords, nb);
+    const size_t lds_bounce = sizeof(int32_t) * (bounceLdsWords(triWords, nb) + (t->split_mesh ? QUEUE_WORDS : 0));
     const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
@@ -1291,6 +1322,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
             bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
             bp.item_count = t->d_item_count + seg0;
+            bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
             const bool fast = !t->no_fast && batched && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo && !bp.emit_count;
             if (first) {
@@ -1313,7 +1345,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
                 else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
             }
         } else {
-            bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0;
+            bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             // the specialised kernel where its assumptions hold (see k_bounce)
             const bool fast = !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo &&
                               !bp.emit_count && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
@@ -1582,7 +1614,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         // (triangle tables, then all tables, to global memory: the plain per-ray loop over the geoms takes over), refuse
         // only what cannot run at all.
         const size_t limit = prop.sharedMemPerBlock;
-        auto need = [&]() { return sizeof(int32_t) * bounceLdsWords(t->tri_lds ? sceneTableWords(t->ntri_lds, nmaterials, ngeoms) : 0, t->nbins); };
+        auto need = [&]() { return sizeof(int32_t) * (bounceLdsWords(t->tri_lds ? sceneTableWords(t->ntri_lds, nmaterials, ngeoms) : 0, t->nbins) + QUEUE_WORDS); };
         if (need() > limit && t->ntri_lds) t->ntri_lds = 0;
         if (need() > limit && t->tri_lds) t->tri_lds = 0;
         if (need() > limit) {
@@ -1743,6 +1775,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             HC(hipMalloc(&t->d_keys, sizeof(unsigned long long) * (size_t)t->cap * nseg));
             HC(hipMalloc(&t->d_items, sizeof(uint32_t) * t->seg_items * nseg));
             HC(hipMalloc(&t->d_item_count, sizeof(int32_t) * nseg));
+            if (!getenv("PTX_DEBUG_NO_FIRST_FUSION")) {
+                HC(hipMalloc(&t->d_tile_done, sizeof(int32_t) * (size_t)t->maxTiles * nseg));
+                HC(hipMemset(t->d_tile_done, 0, sizeof(int32_t) * (size_t)t->maxTiles * nseg));
+            }
         }
     }
     if (opt.apps_variant) {
