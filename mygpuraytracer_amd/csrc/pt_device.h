@@ -234,6 +234,8 @@ struct DScene {
     const float *__restrict__ bvh_tris;             // 16 floats per leaf triangle
     const int32_t *__restrict__ bvh_root;           // per geom: root node, -1 = plain loop over its faces
     const int32_t *__restrict__ bvh_depth;          // per geom: depth of its tree (root = 0)
+    int32_t bvh_stack;                              // entries per lane of the traversal stack the launch provides (k_mesh): trees of
+                                                    // depth >= this use the skip links
     const float *__restrict__ fnorm;    // 3 floats per face: its world-space geometric normal, computed at upload with the
                                         // arithmetic of meshIntersectionTest (src/intersections.h:237-243) -- used when the
                                         // geom has no bump map; cnorm: 18 floats per geom, the six face normals of a cube
@@ -942,7 +944,7 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
             t = meshTestCore<LDSF>(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
     } else {
         // (a stack, when the caller has one and the tree fits it, buys the front-to-back search)
-        const bool ordered = stack && sc.bvh_depth && sc.bvh_depth[g] < BVH_STACK;
+        const bool ordered = stack && sc.bvh_depth && sc.bvh_depth[g] < sc.bvh_stack;
         t = meshTestCore<LDSF>(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1, 0, 0x7fffffff, ordered ? stack : nullptr, stride);
     }
     if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;

@@ -1073,7 +1073,7 @@ struct ptx_tracer {
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr, *d_bvh_depth = nullptr;   // pt_bvh.h (NULL: no mesh has one)
-    int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0;
+    int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0, bvh_stack = BVH_STACK;
     int mesh_chunks = 1;                                 // see DScene::mesh_chunks
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
     uint32_t bump_bits = 0;
@@ -1127,7 +1127,7 @@ struct ptx_tracer {
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
-        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
+        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.bvh_stack = 0; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
         s.fnorm = d_fnorm; s.cnorm = d_cnorm; s.bump_bits = bump_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         return s;
@@ -1336,7 +1336,10 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             mq.sc = t->scene();                                   // tables in global memory
             mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
             mq.seg_stage = bp.seg_stage; mq.seg_keys = bp.seg_keys; mq.seg_items = bp.seg_items;
-            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), sizeof(int32_t) * BVH_STACK * 256, stream, mq));
+            // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy (62 VGPRs would allow 8 waves per
+            // SIMD, 32 entries x 256 lanes x 4 B = 32 KB per workgroup only 5): as many entries as the deepest tree needs
+            mq.sc.bvh_stack = t->bvh_stack;
+            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
             if (first) {
                 if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
                 else KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
@@ -1591,6 +1594,11 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
                 t->bvh_meshes++;
             }
         t->bvh_nodes = (int)(bb.nodes.size() / 2);
+        {   // stack entries per lane for k_mesh: deepest tree + 1 (a tree of depth d needs d + 1), at least 8, at most BVH_STACK
+            int deepest = 0;
+            for (int i = 0; i < ngeoms; i++) if (roots[i] >= 0 && depths[i] < BVH_STACK) deepest = std::max(deepest, depths[i]);
+            t->bvh_stack = std::min(BVH_STACK, std::max(8, deepest + 1));
+        }
         if (!t->bvh_meshes && !getenv("PTX_DEBUG_NO_CHUNKS"))          // spread the loops of small meshes over lanes (tileIntersect)
             for (int i = 0; i < ngeoms; i++)
                 if (hg[i].type == G_OBJ) t->mesh_chunks = std::max(t->mesh_chunks, (hg[i].faceCount + MESH_CHUNK - 1) / MESH_CHUNK);
