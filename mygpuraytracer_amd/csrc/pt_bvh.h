@@ -37,7 +37,7 @@
 // The traversal (bvhNearest) lives in pt_device.h next to the triangle test; this header is the host-side builder.
 // Layout ("threaded" preorder, no stack): node = 2 x 16 bytes {lo.xyz, skip}{hi.xyz, leaf}.  skip = the next node
 // when this one is missed or is a leaf (-1 = done); an inner node that is hit continues at n + 1.  leaf = count << 28
-// | first (count 0 = inner).  Leaf triangles are stored in leaf order, 16 floats each: v0, e1, e2 (as tri9), the
+// | first (count 0 = inner, the low bits then name its right child).  Leaf triangles are stored in leaf order, 16 floats each: v0, e1, e2 (as tri9), the
 // vertices p1, p2 the reference interpolates the hit point from, and the face index inside the geom.
 #pragma once
 #include "pt_device.h"
@@ -179,7 +179,9 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
             hi[k] = nextafterf((float)(nd.hi[k] + m), INFINITY);
         }
         BvhQuad A{lo[0], lo[1], lo[2], skip[i]};
-        BvhQuad B{hi[0], hi[1], hi[2], nd.count ? (int32_t)(((uint32_t)nd.count << 28) | (uint32_t)(tbase + nd.first)) : 0};
+        // leaf: count << 28 | first triangle; inner node: its right child (count bits 0) -- the left child is n + 1, so a visit
+        // can request both children's boxes at once instead of learning the right child from the left child's skip link
+        BvhQuad B{hi[0], hi[1], hi[2], nd.count ? (int32_t)(((uint32_t)nd.count << 28) | (uint32_t)(tbase + nd.first)) : (int32_t)(base + nd.right)};
         out.nodes[2 * (base + i)] = A; out.nodes[2 * (base + i) + 1] = B;
     }
     out.tris.resize(out.tris.size() + (size_t)faceCount * 16);

@@ -550,9 +550,8 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
                 }
             }
         } else {
-            const int L = n + 1;
-            const BvhQuad LA = nodes[2 * L], LB = nodes[2 * L + 1];
-            const int R = LA.w;                                   // the left child's skip link is its sibling
+            const int L = n + 1, R = B.w & 0x0fffffff;             // (the right child is named in the node: both children's
+            const BvhQuad LA = nodes[2 * L], LB = nodes[2 * L + 1];   //  boxes are requested together, one round trip)
             const BvhQuad RA = nodes[2 * R], RB = nodes[2 * R + 1];
             float tl, tr;
             const bool hl = entry(LA, LB, tl), hr = entry(RA, RB, tr);
