@@ -1878,7 +1878,11 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     if (t->lanes > 1 && count < t->lanes * t->kmax) {
         const long long owned = std::max(t->tm.owned, 1);
         const int kmin = (int)std::min<long long>(t->kmax, (t->split_min_paths + owned - 1) / owned);
-        kb = std::min(t->kmax, std::max(kmin, (count + t->lanes - 1) / t->lanes));
+        // ... and into TWO sets rather than three while two can hold the call: a one-shot of three sets starts its third
+        // late (the host issues the sets one after the other) and makes all of them smaller -- 20 iterations as 10 + 10
+        // instead of 7 + 7 + 6: full frame equal, 1/2 tile -2 %, 1/4 and 1/8 tile -7 % (tools/gpu_short_tile_sweep.py)
+        const int nsets = count <= 2 * t->kmax ? std::min(2, t->lanes) : t->lanes;
+        kb = std::min(t->kmax, std::max(kmin, (count + nsets - 1) / nsets));
     }
     const int nl = (t->lanes > 1 && !t->ktiming && t->capture_bounce < 0 && count > kb) ? t->lanes : 1;
     auto fork = [&]() -> int {                           // the other lanes start after what is on the main stream so far
