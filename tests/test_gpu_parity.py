@@ -1164,3 +1164,27 @@ def test_specialised_and_general_bounce_kernels_agree(gpu_product, monkeypatch, 
     with gpu_product.Tracer(s, **opt) as B:
         B.render(1, 5)
         assert beq(B.read_image(), img) and B.stats()["rays_total"] == st["rays_total"]
+
+
+def test_several_devices_apps_variant(gpu_product, O):
+    """The apps/src variant (x PI gather, albedo AOV of iteration 1) through ptx_multi_*: every device holds its own rows of the AOV,
+    ptx_multi_read_albedo merges them; frame and AOV equal the oracle's tiles assembled."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellGlass.txt"), res=(80, 52), depth=6)
+    s.apply_runcuda_camera()
+    d = s.dump()
+    O.set_libm(1); O.create(d, d["textures"]); O.set_apps_variant(1)
+    img = alb = None
+    try:
+        for rank in range(3):
+            O.set_tile(8, rank, 3); O.pt_init()
+            for it in (1, 2, 3):
+                O.iterate(it)
+            img = O.image().copy() if img is None else img + O.image()
+            alb = O.albedo().copy() if alb is None else alb + O.albedo()          # disjoint rows, zeros elsewhere
+    finally:
+        O.set_tile(0, 0, 1); O.set_apps_variant(0)
+    with pt.MultiTracer(s, [0, 0, 0], apps_variant=1) as M:
+        M.render(1, 3)
+        assert beq(M.read_image(), img)
+        assert beq(M.read_albedo(), alb)
