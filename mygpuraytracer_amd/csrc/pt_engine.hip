@@ -64,6 +64,15 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #ifndef PT_PIPELINE_INPUT
 #define PT_PIPELINE_INPUT 0
 #endif
+#ifndef PT_PARK_STATE
+#define PT_PARK_STATE 1       // specialised unsplit k_bounce: state that is idle during the pair tests waits in LDS, not in registers
+#endif
+#ifndef PT_FAST_WAVES
+#define PT_FAST_WAVES 5       // waves per SIMD the specialised k_bounce variants are compiled for (<= 96 registers)
+#endif
+#ifndef PT_FAST_WAVES_SPLIT
+#define PT_FAST_WAVES_SPLIT 4 // same for the specialised MODE 1 variant, which carries the mesh candidate queue as well
+#endif
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4     // waves per SIMD k_bounce is compiled for (register budget 512 / this)
 #endif
@@ -264,7 +273,7 @@ constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contri
 #endif
 // DEFER: the mesh pairs are not worked off here; the caller gets the best key over cubes and spheres and the ray's
 // mesh candidates (split mesh search, see k_mesh), and `hit` is left alone.
-template <bool DEFER>
+template <bool DEFER, bool PARK = false>
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
                                               int32_t *tcnt, int &q, int tid, int lane, int wave, unsigned long long &key_out,
                                               uint32_t &mesh_out TI_ARGS) {
@@ -366,6 +375,11 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     }
     // no barrier here: the caller passes at least two before it touches `scratch` again
     key_out = best[tid];
+    if (PARK) {                                    // the ray was not kept in registers across the pair tests: take the LDS copy
+        asm volatile("" ::: "memory");
+        ray.o = V3(rayb[0 * TILE + tid], rayb[1 * TILE + tid], rayb[2 * TILE + tid]);
+        ray.d = V3(rayb[3 * TILE + tid], rayb[4 * TILE + tid], rayb[5 * TILE + tid]);
+    }
     if (!DEFER) decodeKey(sc, gtab, key_out, ray, need_uv, hit);
     TI_STAMP(7);
 }
@@ -399,7 +413,7 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
 // FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
-__global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BounceParams p_in) {
+__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
     BounceParams p = p_in;
     if (FAST && MODE != 0) {             // the two halves of the split bounce: the subset that holds for textured BVH scenes too
         p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
@@ -595,7 +609,28 @@ __global__ __launch_bounds__(TILE, PT_BOUNCE_WAVES) void k_bounce(const BouncePa
                 if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
                                      p.uses_uv != 0, hit);
                 __syncthreads();                                  // histogram zeroed
-            } else if (p.sc.cull) tileIntersect<false>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
+            } else if (p.sc.cull) {
+                // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 96 registers.  The thread's own state
+                // that is only needed again after the intersection -- throughput colour and pixel slot; the ray itself is in
+                // tileIntersect's LDS copy anyway -- therefore waits in a free part of the record buffer instead of in
+                // registers: the pair tests are where the register demand peaks.  (MODE 1 needs more than parking frees and
+                // stays at 4 waves, where parking only costs LDS traffic; MODE 2 fits 96 registers as it is.)
+                constexpr bool PARK = FAST && PT_PARK_STATE;
+                float *park = reinterpret_cast<float *>(rec) + 12 * TILE;
+                if (PARK) {
+                    park[0 * TILE + tid] = ps.color.x; park[1 * TILE + tid] = ps.color.y; park[2 * TILE + tid] = ps.color.z;
+                    rec[15 * TILE + tid] = pix;
+                }
+                tileIntersect<false, PARK>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
+                if (PARK) {
+                    asm volatile("" ::: "memory");
+                    const float *rb = reinterpret_cast<const float *>(rec);
+                    ps.o = V3(rb[0 * TILE + tid], rb[1 * TILE + tid], rb[2 * TILE + tid]);
+                    ps.d = V3(rb[3 * TILE + tid], rb[4 * TILE + tid], rb[5 * TILE + tid]);
+                    ps.color = V3(park[0 * TILE + tid], park[1 * TILE + tid], park[2 * TILE + tid]);
+                    pix = rec[15 * TILE + tid];
+                }
+            }
             else {
                 if (alive) intersectScene(p.sc, ray, hit);
                 __syncthreads();                                  // histogram zeroed (tileIntersect has barriers of its own)
