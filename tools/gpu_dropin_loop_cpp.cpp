@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
     auto t2 = std::chrono::steady_clock::now();
     double a = std::chrono::duration<double, std::milli>(t1 - t0).count() / N, b = std::chrono::duration<double, std::milli>(t2 - t1).count() / N;
     printf("{\"ms_per_pathtrace_call_with_frame_readback\": %.3f, \"with_preview_too\": %.3f, \"pinned\": %s, \"checksum\": %.6g}\n", a, b,
-           (argc > 3 && std::string(argv[3]) == "nopin") ? "false" : "true", (double)scene->state.image[1000].x);
+           (argc > 3 && std::string(argv[3]) == "nopin") ? "false" : "true", (double)scene->state.image[1000].x + (double)scene->state.image[(size_t)1920 * 540 + 960].y);
     pathtraceFree();
     return 0;
 }
