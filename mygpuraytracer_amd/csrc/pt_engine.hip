@@ -1092,7 +1092,8 @@ struct ptx_tracer {
     DCamera cam{};
     int traceDepth = 0;
     TileMap tm{};
-    int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, cap = 0;
+    int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, cap = 0, cus = 0;
+    bool grid_forced = false;                  // PTX_DEBUG_WG_PER_CU given: the grid is what it says for every kernel
     // device memory
     DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
     float *d_image = nullptr; bool own_image = false;
@@ -1273,10 +1274,15 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
     const bool fill_cache = cache_on && !use_cache;
     const bool batched = K > 1 || t->lanes > 1;      // ending paths store into per-iteration buffers, k_gather sums them
-    int gx = t->grid / K;                            // workgroups per segment
+    // the specialised unsplit kernel runs 5 workgroups per CU at a time: a grid of 8 per CU would be 1.6 rounds of them (C4 -1.3 %)
+    const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material &&
+                              !t->d_albedo && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
+                              !t->d_bvh_root;
+    const int grid = fast_unsplit && !t->grid_forced ? std::min(t->grid, t->cus * PT_FAST_WAVES) : t->grid;
+    int gx = grid / K;                               // workgroups per segment
     if (gx < 64) gx = 64;
     if (gx > t->maxTiles) gx = t->maxTiles;
-    if (gx > t->grid) gx = t->grid;
+    if (gx > grid) gx = grid;
     if (gx < 1) gx = 1;
     const int nsuper = (gx + 63) / 64;
     const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * (size_t)nb * t->grid, seg_totals = t->seg_totals;
@@ -1385,9 +1391,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             // the specialised kernel where its assumptions hold (see k_bounce)
-            const bool fast = !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo &&
-                              !bp.emit_count && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
-                              !t->d_bvh_root;
+            const bool fast = fast_unsplit && !bp.emit_count;
             if (first) {
                 if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
                 else KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
@@ -1570,7 +1574,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipGetDeviceProperties(&prop, dev));
     {
         int per_cu = 2048 / TILE;
-        if (const char *e = getenv("PTX_DEBUG_WG_PER_CU")) per_cu = std::max(1, atoi(e));      // tuning experiments only
+        if (const char *e = getenv("PTX_DEBUG_WG_PER_CU")) { per_cu = std::max(1, atoi(e)); t->grid_forced = true; }      // tuning experiments only
+        t->cus = prop.multiProcessorCount;
         t->grid = std::min(t->maxTiles, prop.multiProcessorCount * per_cu);
     }
     if (t->grid < 1) t->grid = 1;
