@@ -133,6 +133,33 @@ __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
 // The same stream, but with a stride the optimiser cannot see through: field addresses derived from the result are
 // computed where they are used (a few scalar adds per tile) instead of being hoisted out of the tile loop and kept --
 // 34 scalar registers per stream -- for its whole length.
+// Uniform base + per-lane 32-bit byte offset: the form the hardware addresses by itself (global_load_dword v, voffset,
+// s[base:base+1]).  Written as base[index] the compiler forms a 64-bit address per access in vector registers (one
+// v_lshl_add_u64 and a register pair each); this way a record's 15 fields share one offset register and the per-field
+// bases are scalar adds.  The base must be wave-uniform and the offset below 4 GiB (a segment's field is capacity x 4 B).
+#ifndef PT_SCALAR_BASE
+#define PT_SCALAR_BASE 1
+#endif
+template <class T> using gptr = T __attribute__((address_space(1))) *;
+template <class T> __device__ __forceinline__ T ld_u(const T *base, uint32_t byteoff) {
+#if PT_SCALAR_BASE
+    gptr<const T> b = (gptr<const T>)base;
+    asm volatile("" : "+s"(b));
+    return *reinterpret_cast<gptr<const T>>(reinterpret_cast<gptr<const char>>(b) + byteoff);
+#else
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byteoff);
+#endif
+}
+template <class T> __device__ __forceinline__ void st_u(T *base, uint32_t byteoff, T v) {
+#if PT_SCALAR_BASE
+    gptr<T> b = (gptr<T>)base;
+    asm volatile("" : "+s"(b));
+    *reinterpret_cast<gptr<T>>(reinterpret_cast<gptr<char>>(b) + byteoff) = v;
+#else
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byteoff) = v;
+#endif
+}
+
 __device__ __forceinline__ PathSoA soa_fresh(PathSoA s) {
     asm volatile("" : "+s"(s.stride));
     return s;
@@ -216,8 +243,8 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 __device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, bool batched, int pix, vec3 c, int apps) {
     if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
     if (batched) {
-        float *px = part + (size_t)pix * 3;
-        px[0] = c.x; px[1] = c.y; px[2] = c.z;
+        const uint32_t o = (uint32_t)pix * 12u;
+        st_u(part, o, c.x); st_u(part + 1, o, c.y); st_u(part + 2, o, c.z);
     } else {
         float *px = image + (size_t)slot_to_pixel(tm, pix) * 3;
         px[0] += c.x; px[1] += c.y; px[2] += c.z;
@@ -474,13 +501,14 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA in = soa_fresh(in_k);
         const int jp = min(tile_ * TILE + tid, n_in - 1);
         // the sorted stream is not materialised: position jp of it is slot j of the previous bounce's stage
-        const int j = (p.perm_src + p.seg_perm * seg)[jp];
-        r.idx = (p.perm_idx + p.seg_perm * seg)[jp];
+        const uint32_t jp4 = (uint32_t)jp << 2;
+        const uint32_t j4 = (uint32_t)ld_u(p.perm_src + p.seg_perm * seg, jp4) << 2;
+        r.idx = ld_u(p.perm_idx + p.seg_perm * seg, jp4);
 #pragma unroll
-        for (int k = 0; k < 12; k++) r.f[k] = in.field(k)[j];
+        for (int k = 0; k < 12; k++) r.f[k] = ld_u(in.field(k), j4);
         r.f[12] = r.f[13] = 0.f;
-        if (p.uses_uv) { r.f[12] = in.u()[j]; r.f[13] = in.v()[j]; }
-        r.pix = in.pix()[j]; r.mg = in.mg()[j];
+        if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
+        r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
     };
     if (PIPE && tile0 < tile1) fetch(tile0, nxt);
     for (int tile = tile0; tile < tile1; tile++) {
@@ -763,19 +791,17 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         {
             const PathSoA stage = soa_fresh(stage_k);
             const int npend = toff[nb];
-            const size_t gi = (size_t)tile * TILE + tid;
+            const uint32_t gi4 = (uint32_t)(tile * TILE + tid) << 2;
             if (tid < npend) {
                 const float *rf = reinterpret_cast<const float *>(rec);
-                stage.px()[gi] = rf[0 * TILE + tid]; stage.py()[gi] = rf[1 * TILE + tid]; stage.pz()[gi] = rf[2 * TILE + tid];
-                stage.dx()[gi] = rf[3 * TILE + tid]; stage.dy()[gi] = rf[4 * TILE + tid]; stage.dz()[gi] = rf[5 * TILE + tid];
-                stage.cr()[gi] = rf[6 * TILE + tid]; stage.cg()[gi] = rf[7 * TILE + tid]; stage.cb()[gi] = rf[8 * TILE + tid];
-                stage.nx()[gi] = rf[9 * TILE + tid]; stage.ny()[gi] = rf[10 * TILE + tid]; stage.nz()[gi] = rf[11 * TILE + tid];
-                if (p.uses_uv) { stage.u()[gi] = rf[12 * TILE + tid]; stage.v()[gi] = rf[13 * TILE + tid]; }
-                stage.pix()[gi] = rec[14 * TILE + tid];
-                stage.mg()[gi] = rec[15 * TILE + tid];
-                stage.idx()[gi] = rec[16 * TILE + tid];
+#pragma unroll
+                for (int k = 0; k < 12; k++) st_u(stage.field(k), gi4, rf[k * TILE + tid]);
+                if (p.uses_uv) { st_u(stage.u(), gi4, rf[12 * TILE + tid]); st_u(stage.v(), gi4, rf[13 * TILE + tid]); }
+                st_u(stage.pix(), gi4, rec[14 * TILE + tid]);
+                st_u(stage.mg(), gi4, rec[15 * TILE + tid]);
+                st_u(stage.idx(), gi4, rec[16 * TILE + tid]);
             } else {
-                stage.idx()[gi] = -1;
+                st_u(stage.idx(), gi4, (int32_t)-1);
             }
         }
         __syncthreads();
@@ -881,17 +907,18 @@ __global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
             const int tile = tbase + u;
-            key[u] = tile < tile1 ? keys[(size_t)tile * TILE + tid] : -1;
+            key[u] = tile < tile1 ? ld_u(keys, (uint32_t)(tile * TILE + tid) << 2) : -1;
         }
 #pragma unroll
         for (int u = 0; u < MOVE_U; u++) {
             if (key[u] == -1) continue;
             const int tile = tbase + u;
             const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
-            const int idx = base_all[bin] + counts_all[(size_t)bin * p.maxTiles + tile] + r_all;
-            const int pos = base_scat[bin] + counts_scat[(size_t)bin * p.maxTiles + tile] + r_scat;
-            perm_src[pos] = tile * TILE + tid;
-            perm_idx[pos] = idx;
+            const uint32_t c4 = (uint32_t)(bin * p.maxTiles + tile) << 2;      // (a segment's table is below 4 GiB: ptx_create)
+            const int idx = base_all[bin] + ld_u(counts_all, c4) + r_all;
+            const int pos = base_scat[bin] + ld_u(counts_scat, c4) + r_scat;
+            st_u(perm_src, (uint32_t)pos << 2, (int32_t)(tile * TILE + tid));
+            st_u(perm_idx, (uint32_t)pos << 2, (int32_t)idx);
         }
     }
 }
@@ -1092,7 +1119,7 @@ struct ptx_tracer {
     DCamera cam{};
     int traceDepth = 0;
     TileMap tm{};
-    int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, cap = 0, cus = 0;
+    int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, grid_seg = 0, cap = 0, cus = 0;
     bool grid_forced = false;                  // PTX_DEBUG_WG_PER_CU given: the grid is what it says for every kernel
     // device memory
     DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
@@ -1285,7 +1312,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     if (gx > grid) gx = grid;
     if (gx < 1) gx = 1;
     const int nsuper = (gx + 63) / 64;
-    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * (size_t)nb * t->grid, seg_totals = t->seg_totals;
+    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * (size_t)nb * t->grid_seg, seg_totals = t->seg_totals;
     int32_t *counts_all = t->d_counts + seg0 * seg_counts, *counts_scat = counts_all + (size_t)nb * t->maxTiles;
     int32_t *chunk_all = t->d_chunk + seg0 * seg_chunk, *chunk_scat = chunk_all + (size_t)nb * gx;
     auto totals = [&](int bounce, int which) { return t->d_totals + seg0 * seg_totals + ((size_t)bounce * 2 + which) * nb; };
@@ -1576,9 +1603,12 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         int per_cu = 2048 / TILE;
         if (const char *e = getenv("PTX_DEBUG_WG_PER_CU")) { per_cu = std::max(1, atoi(e)); t->grid_forced = true; }      // tuning experiments only
         t->cus = prop.multiProcessorCount;
+        // (also for K segments in one launch: a 1/8 tile's ten iterations as 10 x 101 workgroups of 10 tiles run 6 % FASTER than as
+        // 10 x 128 of 8 -- a grid that does not quite fill the chip leaves room for the other launch set's kernel to start)
         t->grid = std::min(t->maxTiles, prop.multiProcessorCount * per_cu);
     }
     if (t->grid < 1) t->grid = 1;
+    t->grid_seg = std::max(1, std::min(t->grid, t->maxTiles));      // what one segment (iteration) can use: sizes its tables
     if (stream) { t->stream = (hipStream_t)stream; t->own_stream = false; }
     else {
         // the main stream carries what a caller waits for (per-call gather, preview, frame read-back) while the other lanes
@@ -1845,8 +1875,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMemset(t->d_albedo, 0, sizeof(float) * 3 * npix));
     }
     HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * nseg));
-    t->nsuper = (t->grid + 63) / 64;
-    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid * nseg));
+    t->nsuper = (t->grid_seg + 63) / 64;
+    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid_seg * nseg));
     t->seg_totals = 2 * (size_t)t->nbins * t->maxBounces * (1 + (size_t)t->nsuper);
     t->totals_bytes = sizeof(int32_t) * t->seg_totals * nseg;
     HC(hipMalloc(&t->d_totals, t->totals_bytes));
@@ -1944,8 +1974,11 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
     if (nl > 1) { int rc = fork(); if (rc != PTX_OK) return rc; }
     int batch = 0, prev_lane = -1;
     bool used[MAX_LANES] = {};
+    int first_set = 0;
+    if (const char *e = getenv("PTX_DEBUG_FIRST_SET")) first_set = atoi(e);      // tuning experiments only
     for (int k = 0; k < count; batch++) {
         int K = std::min(nl > 1 ? kb : t->kmax, count - k);
+        if (nl > 1 && first_set > 0 && count <= 2 * t->kmax) K = std::min(batch == 0 ? std::min(first_set, t->kmax) : t->kmax, count - k);
         if (t->capture_bounce >= 0) K = 1;                        // the debug capture looks at one stream
         if (t->cache_active() && (!t->cache_valid || iter_first + k * stride == 1)) K = 1;
         const int lane = nl > 1 ? batch % nl : 0;
