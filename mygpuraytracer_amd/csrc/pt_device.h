@@ -1096,6 +1096,10 @@ struct PathState {
 
 // scatterRay, src/interactions.h:111-256.  Returns true when the OBJ emissive-texel branch ended the path
 // (the reference sets remainingBounces = 1 there and its caller decrements it to 0).
+// TEX = false: the scene has no texture at all (every DTex::ch is 0), so the texel branches and the loads that decide them are
+// left out.  The two diffuse cases -- an OBJ geom's and everything else's -- share one copy of the hemisphere sampler: a wave
+// that holds both kinds of hit runs it once, and the kernel holds its binary64 sin/cos once.
+template <bool TEX = true>
 PT_DEV bool scatterRay(const DScene &sc, PathState &ps, vec3 intersect, const Hit &hit, const DMaterial &m, Rng &rng) {
     vec3 n = hit.n;
     if (m.hasReflective > 0) {
@@ -1127,54 +1131,53 @@ PT_DEV bool scatterRay(const DScene &sc, PathState &ps, vec3 intersect, const Hi
         ps.d = nd;
         ps.color = mul(ps.color, V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]));
         ps.o = add(intersect, scale(nd, 0.01f));
-    } else if (geomType(sc, hit.geom) == G_OBJ) {
-        const DGeom &geom = sc.geoms[hit.geom];
-        const DTex &kd = geom.tex[0], &ks = geom.tex[1], &ke = geom.tex[2];
-        vec3 emission = V3(0.f, 0.f, 0.f);
-        if (ke.ch) {
-            int coordU = (int)(hit.u * ke.w);
-            int coordV = (int)(hit.v * ke.h);
-            int pixelID = coordV * ke.w + coordU;
-            emission = V3(texel(sc, ke, pixelID, 0) / 255.f, texel(sc, ke, pixelID, 1) / 255.f, texel(sc, ke, pixelID, 2) / 255.f);
-        }
-        const float eps = 1.1920928955078125e-07f;
-        if (emission.x > eps || emission.y > eps || emission.z > eps) {
-            ps.color = mul(ps.color, scale(emission, 5.0f));
-            return true;
-        }
-        float cosTheta = dot(neg(ps.d), n);
-        float reflect_coeff = schlick(1.0f, m.ior, cosTheta);
-        float random = rng.uniform(0.f, 1.f);
-        if (random < reflect_coeff) {
-            int coordU = (int)(hit.u * ks.w);
-            int coordV = (int)(hit.v * ks.h);
-            int pixelID = coordV * ks.w + coordU;
-            vec3 reflectDir = reflect(ps.d, n);
-            float spec = 1.0f;      // glm::pow(x, 0.0f) == 1 for every x (src/interactions.h:203)
-            vec3 specColor;
-            if (ks.ch) specColor = V3(texel(sc, ks, pixelID, 0) / 255.f, texel(sc, ks, pixelID, 1) / 255.f, texel(sc, ks, pixelID, 2) / 255.f);
-            else specColor = V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]);
-            specColor = scale(specColor, spec);
-            ps.color = mul(ps.color, specColor);
-            ps.o = add(intersect, scale(n, 0.01f));
-            ps.d = reflectDir;
-        } else {
-            int coordU = (int)(hit.u * kd.w);
-            int coordV = (int)(hit.v * kd.h);
-            int pixelID = coordV * kd.w + coordU;
-            vec3 diffuseColor;
-            if (kd.ch) diffuseColor = V3(texel(sc, kd, pixelID, 0) / 255.f, texel(sc, kd, pixelID, 1) / 255.f, texel(sc, kd, pixelID, 2) / 255.f);
-            else diffuseColor = V3(m.color[0], m.color[1], m.color[2]);
-            ps.color = mul(ps.color, diffuseColor);
-            vec3 nd = randomDirectionInHemisphere(n, rng);
-            ps.d = nd;
-            ps.o = add(intersect, scale(nd, 0.01f));
-        }
     } else {
+        vec3 diffuseColor = V3(m.color[0], m.color[1], m.color[2]);
+        if (geomType(sc, hit.geom) == G_OBJ) {
+            const DGeom &geom = sc.geoms[hit.geom];
+            const DTex &kd = geom.tex[0], &ks = geom.tex[1], &ke = geom.tex[2];
+            vec3 emission = V3(0.f, 0.f, 0.f);
+            if (TEX && ke.ch) {
+                int coordU = (int)(hit.u * ke.w);
+                int coordV = (int)(hit.v * ke.h);
+                int pixelID = coordV * ke.w + coordU;
+                emission = V3(texel(sc, ke, pixelID, 0) / 255.f, texel(sc, ke, pixelID, 1) / 255.f, texel(sc, ke, pixelID, 2) / 255.f);
+            }
+            const float eps = 1.1920928955078125e-07f;
+            if (TEX && (emission.x > eps || emission.y > eps || emission.z > eps)) {
+                ps.color = mul(ps.color, scale(emission, 5.0f));
+                return true;
+            }
+            float cosTheta = dot(neg(ps.d), n);
+            float reflect_coeff = schlick(1.0f, m.ior, cosTheta);
+            float random = rng.uniform(0.f, 1.f);
+            if (random < reflect_coeff) {
+                vec3 reflectDir = reflect(ps.d, n);
+                float spec = 1.0f;      // glm::pow(x, 0.0f) == 1 for every x (src/interactions.h:203)
+                vec3 specColor = V3(m.speccolor[0], m.speccolor[1], m.speccolor[2]);
+                if (TEX && ks.ch) {
+                    int coordU = (int)(hit.u * ks.w);
+                    int coordV = (int)(hit.v * ks.h);
+                    int pixelID = coordV * ks.w + coordU;
+                    specColor = V3(texel(sc, ks, pixelID, 0) / 255.f, texel(sc, ks, pixelID, 1) / 255.f, texel(sc, ks, pixelID, 2) / 255.f);
+                }
+                specColor = scale(specColor, spec);
+                ps.color = mul(ps.color, specColor);
+                ps.o = add(intersect, scale(n, 0.01f));
+                ps.d = reflectDir;
+                return false;
+            }
+            if (TEX && kd.ch) {
+                int coordU = (int)(hit.u * kd.w);
+                int coordV = (int)(hit.v * kd.h);
+                int pixelID = coordV * kd.w + coordU;
+                diffuseColor = V3(texel(sc, kd, pixelID, 0) / 255.f, texel(sc, kd, pixelID, 1) / 255.f, texel(sc, kd, pixelID, 2) / 255.f);
+            }
+        }
+        ps.color = mul(ps.color, diffuseColor);
         vec3 nd = randomDirectionInHemisphere(n, rng);
         ps.d = nd;
         ps.o = add(intersect, scale(nd, 0.01f));
-        ps.color = mul(ps.color, V3(m.color[0], m.color[1], m.color[2]));
     }
     return false;
 }

@@ -573,7 +573,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 STAMP(11);
 #endif
                 Rng rng; rng.seed(iter, sidx, 0);
-                bool ended = scatterRay(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
+                bool ended = (FAST && MODE == 0) ? scatterRay<false>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng)
+                                                 : scatterRay<true>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
                 if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
                     deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps);
                     alive = false;
