@@ -231,7 +231,9 @@ struct DScene {
                                         // triangle test starts with, done once at upload: same IEEE results)
     const uint8_t *__restrict__ texels;
     int32_t ngeoms, nmats;
-    int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS
+    int32_t tri_lds;                    // != 0: the kernel has staged the scene tables at the start of its dynamic LDS; 2 (set as a
+                                        // constant by the specialised kernel): the triangle tables too, whatever ntri is -- the
+                                        // global-memory variants of the table reads are then not even compiled (triLds below)
                                         // (pt_lds): tri9 [ntri_lds*9], faces [ntri_lds*15], materials [nmats*11], gtab [ngeoms*40],
                                         // fnorm [ntri_lds*3], cnorm [ngeoms*18]
     int32_t ntri;
@@ -281,9 +283,11 @@ __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int n
     for (int k = tid; k < nf; k += nthreads) l[n9 + n15 + nm + ng + k] = sc.fnorm[k];
     for (int k = tid; k < nc; k += nthreads) l[n9 + n15 + nm + ng + nf + k] = sc.cnorm[k];
 }
+// are the triangle tables (tri9, faces, fnorm) staged in LDS?
+PT_DEV bool triLds(const DScene &sc) { return sc.tri_lds == 2 || (sc.tri_lds && sc.ntri_lds); }
 // precomputed normals: face `face` (global index) of the meshes / side `side` of cube `g`
 PT_DEV vec3 faceNormalTab(const DScene &sc, int face) {
-    if (sc.tri_lds && sc.ntri_lds) {
+    if (triLds(sc)) {
         const float *l = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11 + sc.ngeoms * GTAB_WORDS + face * 3;
         return V3(l[0], l[1], l[2]);
     }
@@ -321,7 +325,7 @@ PT_DEV DMaterial getMaterial(const DScene &sc, int id) {
 }
 // word k of the 15-float record (3 x pos xyz, uv) of triangle `face` (global index)
 PT_DEV float faceWord(const DScene &sc, int face, int k) {
-    if (sc.tri_lds && sc.ntri_lds) return reinterpret_cast<const float *>(pt_lds)[sc.ntri_lds * 9 + face * 15 + k];
+    if (triLds(sc)) return reinterpret_cast<const float *>(pt_lds)[sc.ntri_lds * 9 + face * 15 + k];
     return sc.faces[(size_t)face * 15 + k];
 }
 PT_DEV vec3 faceVec(const DScene &sc, int face, int k) { return V3(faceWord(sc, face, k), faceWord(sc, face, k + 1), faceWord(sc, face, k + 2)); }
@@ -615,7 +619,7 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
     if (j1 > geom.faceCount) j1 = geom.faceCount;
     for (int j = j0; j < j1; j++) {       // (the whole face list unless the caller spreads it over lanes)
         vec3 v0, e1, e2;
-        if (LDSF || (sc.tri_lds && sc.ntri_lds)) {      // broadcast ds_reads: every lane reads the same triangle
+        if (LDSF || triLds(sc)) {      // broadcast ds_reads: every lane reads the same triangle
             const float *t9 = reinterpret_cast<const float *>(pt_lds) + (size_t)(geom.faceStart + j) * 9;
             v0 = V3(t9[0], t9[1], t9[2]); e1 = V3(t9[3], t9[4], t9[5]); e2 = V3(t9[6], t9[7], t9[8]);
         } else {
@@ -627,7 +631,7 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
             const int f = geom.faceStart + j;
             // the face record (3 x pos xyz, uv) of the hit, through ONE pointer (LDS when the caller said so at compile time)
             const float *F = LDSF ? reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 9 + f * 15
-                                  : ((sc.tri_lds && sc.ntri_lds) ? reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 9 + f * 15 : sc.faces + (size_t)f * 15);
+                                  : (triLds(sc) ? reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 9 + f * 15 : sc.faces + (size_t)f * 15);
             vec3 p1 = V3(F[5], F[6], F[7]), p2 = V3(F[10], F[11], F[12]);
             float w = 1 - b0 - b1;
             vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));

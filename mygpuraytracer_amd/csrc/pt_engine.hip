@@ -68,10 +68,14 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #define PT_PARK_STATE 1       // specialised unsplit k_bounce: state that is idle during the pair tests waits in LDS, not in registers
 #endif
 #ifndef PT_FAST_WAVES
-#define PT_FAST_WAVES 5       // waves per SIMD the specialised k_bounce variants are compiled for (<= 96 registers)
+#define PT_FAST_WAVES 7       // waves per SIMD the specialised k_bounce variants are compiled for (<= 72 registers; 7 workgroups'
+                              // LDS is also what a CU holds with the Cornell tables)
 #endif
 #ifndef PT_FAST_WAVES_SPLIT
 #define PT_FAST_WAVES_SPLIT 4 // same for the specialised MODE 1 variant, which carries the mesh candidate queue as well
+#endif
+#ifndef PT_FAST_WAVES_SPLIT2
+#define PT_FAST_WAVES_SPLIT2 5 // and for MODE 2 (fits 6-7 as it is; a tighter bound measured 1-2 % slower on C5)
 #endif
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4     // waves per SIMD k_bounce is compiled for (register budget 512 / this)
@@ -240,11 +244,23 @@ __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
 // A path that ends adds its radiance to its pixel (finalGather, src/pathtrace.cu:407-416).  Each pixel ends exactly
 // once per iteration, so this is a plain read-modify-write, or -- when several iterations are in flight as
 // segments of one launch -- a plain store into that iteration's buffer.
+// three floats stored by one instruction (global_store_dwordx3 with a scalar base); the address is only 4-byte aligned
+typedef float Rgb __attribute__((ext_vector_type(3)));
+typedef Rgb RgbUnaligned __attribute__((aligned(4)));
+__device__ __forceinline__ void st_rgb(float *base, uint32_t byteoff, float r, float g, float b) {
+    const Rgb v = {r, g, b};
+#if PT_SCALAR_BASE
+    gptr<float> sb = (gptr<float>)base;
+    asm volatile("" : "+s"(sb));
+    *reinterpret_cast<RgbUnaligned __attribute__((address_space(1))) *>(reinterpret_cast<gptr<char>>(sb) + byteoff) = v;
+#else
+    *reinterpret_cast<RgbUnaligned *>(reinterpret_cast<char *>(base) + byteoff) = v;
+#endif
+}
 __device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, bool batched, int pix, vec3 c, int apps) {
     if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
     if (batched) {
-        const uint32_t o = (uint32_t)pix * 12u;
-        st_u(part, o, c.x); st_u(part + 1, o, c.y); st_u(part + 2, o, c.z);
+        st_rgb(part, (uint32_t)pix * 12u, c.x, c.y, c.z);
     } else {
         float *px = image + (size_t)slot_to_pixel(tm, pix) * 3;
         px[0] += c.x; px[1] += c.y; px[2] += c.z;
@@ -390,7 +406,7 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
                 r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
                 r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
                 // (tileIntersect runs with the tables staged; the triangle tables too unless the scene's meshes are too big)
-                const unsigned long long key = k < startM ? primKey(gtab, g, r) : (sc.ntri_lds ? meshKey<true>(sc, gtab, g, r, chunk) : meshKey<false>(sc, gtab, g, r, chunk));
+                const unsigned long long key = k < startM ? primKey(gtab, g, r) : ((sc.tri_lds == 2 || sc.ntri_lds) ? meshKey<true>(sc, gtab, g, r, chunk) : meshKey<false>(sc, gtab, g, r, chunk));
                 if (key != KEY_NONE) atomicMin(&best[src], key);
             }
         }
@@ -440,14 +456,14 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
 // FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
-__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
+__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
     BounceParams p = p_in;
     if (FAST && MODE != 0) {             // the two halves of the split bounce: the subset that holds for textured BVH scenes too
         p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
     }
     if (FAST && MODE == 0) {
         p.uses_uv = 0; p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
-        p.sc.cull = 1; p.sc.tri_lds = 1; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
+        p.sc.cull = 1; p.sc.tri_lds = 2; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
     }
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
@@ -639,7 +655,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                                      p.uses_uv != 0, hit);
                 __syncthreads();                                  // histogram zeroed
             } else if (p.sc.cull) {
-                // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 96 registers.  The thread's own state
+                // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 72 registers.  The thread's own state
                 // that is only needed again after the intersection -- throughput colour and pixel slot; the ray itself is in
                 // tileIntersect's LDS copy anyway -- therefore waits in a free part of the record buffer instead of in
                 // registers: the pair tests are where the register demand peaks.  (MODE 1 needs more than parking frees and
@@ -691,10 +707,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
             // in batched mode the path's slot of the per-iteration buffer must still be written
             if (batched && !pending && !lit) {
-                float *px = part + (size_t)pix * 3;
                 float z = 0.f;
                 asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
-                px[0] = z; px[1] = z; px[2] = z;
+                st_rgb(part, (uint32_t)pix * 12u, z, z, z);
             }
         }
         STAMP(2);        // classify + deposit
