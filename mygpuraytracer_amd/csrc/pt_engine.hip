@@ -406,7 +406,9 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
                 r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
                 r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
                 // (tileIntersect runs with the tables staged; the triangle tables too unless the scene's meshes are too big)
-                const unsigned long long key = k < startM ? primKey(gtab, g, r) : ((sc.tri_lds == 2 || sc.ntri_lds) ? meshKey<true>(sc, gtab, g, r, chunk) : meshKey<false>(sc, gtab, g, r, chunk));
+                // (DEFER: the mesh list stays empty, so its tests are not compiled into that kernel at all)
+                const unsigned long long key = (DEFER || k < startM) ? primKey(gtab, g, r)
+                    : ((sc.tri_lds == 2 || sc.ntri_lds) ? meshKey<true>(sc, gtab, g, r, chunk) : meshKey<false>(sc, gtab, g, r, chunk));
                 if (key != KEY_NONE) atomicMin(&best[src], key);
             }
         }
