@@ -1323,7 +1323,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material &&
                               !t->d_albedo && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
                               !t->d_bvh_root;
-    const int grid = fast_unsplit && !t->grid_forced ? std::min(t->grid, t->cus * PT_FAST_WAVES) : t->grid;
+    // ... the split bounce's kernels are many short ones: 16 workgroups per CU (C5 -2 %); everything else 8 as before
+    const int grid = t->grid_forced ? t->grid : std::min(t->grid, t->cus * (fast_unsplit ? PT_FAST_WAVES : t->split_mesh ? 16 : 8));
     int gx = grid / K;                               // workgroups per segment
     if (gx < 64) gx = 64;
     if (gx > t->maxTiles) gx = t->maxTiles;
@@ -1425,7 +1426,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy (62 VGPRs would allow 8 waves per
             // SIMD, 32 entries x 256 lanes x 4 B = 32 KB per workgroup only 5): as many entries as the deepest tree needs
             mq.sc.bvh_stack = t->bvh_stack;
-            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, t->grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
+            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
             if (first) {
                 if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
                 else KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
@@ -1618,7 +1619,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
 #define HC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(PTX_ERR_HIP); } } while (0)
     HC(hipGetDeviceProperties(&prop, dev));
     {
-        int per_cu = 2048 / TILE;
+        int per_cu = 16;                      // upper bound (sizes the per-workgroup tables); enqueue_batch picks 7, 8 or 16 per CU
         if (const char *e = getenv("PTX_DEBUG_WG_PER_CU")) { per_cu = std::max(1, atoi(e)); t->grid_forced = true; }      // tuning experiments only
         t->cus = prop.multiProcessorCount;
         // (also for K segments in one launch: a 1/8 tile's ten iterations as 10 x 101 workgroups of 10 tiles run 6 % FASTER than as
