@@ -539,13 +539,16 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
     auto entry = [&](const BvhQuad &A, const BvhQuad &B, float &tn) { return slabEntry(A, B, rs, tmin, tn); };       // false = skip
     int sp = 0;
     int n = root;                 // node in hand (its box is tested when it is taken in hand), -1 = pop
+    // The second quad of the node in hand -- leaf range or right child -- travels with it: it was fetched together with the box
+    // when the node was tested, so a level costs ONE round trip to memory (the children's boxes), not two.
+    BvhQuad Bn = nodes[2 * root + 1];
     {
         float tn;
         if (visited) ++*visited;
-        if (!entry(nodes[2 * root], nodes[2 * root + 1], tn)) return tmin;
+        if (!entry(nodes[2 * root], Bn, tn)) return tmin;
     }
     for (;;) {
-        const BvhQuad B = nodes[2 * n + 1];
+        const BvhQuad B = Bn;
         const int count = (int)((uint32_t)B.w >> 28), first = B.w & 0x0fffffff;
         int next = -1;
         if (count) {
@@ -575,15 +578,17 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
                 stack[sp * stride] = left_first ? R : L;
                 sp++;
                 next = left_first ? L : R;
-            } else if (hl) next = L;
-            else if (hr) next = R;
+                Bn = left_first ? LB : RB;
+            } else if (hl) { next = L; Bn = LB; }
+            else if (hr) { next = R; Bn = RB; }
         }
         // pop until a node whose box still matters (the best distance may have shrunk since it was pushed)
         while (next < 0) {
             if (sp == 0) return tmin;
             const int c = stack[--sp * stride];
+            const BvhQuad CA = nodes[2 * c], CB = nodes[2 * c + 1];
             float tn;
-            if (entry(nodes[2 * c], nodes[2 * c + 1], tn)) next = c;
+            if (entry(CA, CB, tn)) { next = c; Bn = CB; }
         }
         n = next;
     }
