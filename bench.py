@@ -289,7 +289,9 @@ def main():
             T.render(first, count)
 
     def barrier():
-        torch.cuda.synchronize()
+        # barrier, then synchronize.  (The RCCL barrier is ordered behind what this rank has enqueued on its current stream -- the
+        # exchange -- so no rank passes it before every rank's part is done; a host synchronize in FRONT of it would only add a
+        # round trip to the timed region.)
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
