@@ -452,7 +452,7 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // per entry in dense, lean waves and folds its keys in with 64-bit atomic minima; MODE 2 picks the rays up again and
 // does the rest (winner's normal, terminal cases, ranking, in-tile sort, stage write).  Same arithmetic, same bits.
 // FAST: the options that are run-time values in the general kernel are compile-time constants for the common case -- no
-// textures, no apps variant, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
+// textures, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
 // of field, batched radiance buffers, not the cache-filling pass -- so that every test of them, and the code behind the
 // untaken side, is gone (C4: k_bounce -6 %, the first bounce -11 %, fewer registers).  The host picks the variant per launch
 // (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
@@ -461,10 +461,10 @@ template <bool FIRST, int MODE, bool FAST = false>
 __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
     BounceParams p = p_in;
     if (FAST && MODE != 0) {             // the two halves of the split bounce: the subset that holds for textured BVH scenes too
-        p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
+        p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
     }
     if (FAST && MODE == 0) {
-        p.uses_uv = 0; p.apps = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
+        p.uses_uv = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
         p.sc.cull = 1; p.sc.tri_lds = 2; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
     }
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
@@ -1320,8 +1320,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const bool fill_cache = cache_on && !use_cache;
     const bool batched = K > 1 || t->lanes > 1;      // ending paths store into per-iteration buffers, k_gather sums them
     // the specialised unsplit kernel runs 5 workgroups per CU at a time: a grid of 8 per CU would be 1.6 rounds of them (C4 -1.3 %)
-    const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && !t->opt.apps_variant && t->opt.sort_by_material &&
-                              !t->d_albedo && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
+    // (the apps variant's x PI at the deposit stays a run-time value in every kernel; its albedo AOV is written by iteration 1 alone,
+    // so only a launch set that contains iteration 1 needs the general kernel for it)
+    const bool needs_albedo = t->d_albedo && iter_first == 1;
+    const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && t->opt.sort_by_material &&
+                              !needs_albedo && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
                               !t->d_bvh_root;
     // ... the split bounce's kernels are many short ones: 16 workgroups per CU (C5 -2 %); everything else 8 as before
     // (traced ahead of per-call requests: two of the seven slots per CU stay free, so that the caller's own short kernels -- gather,
@@ -1413,7 +1416,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.item_count = t->d_item_count + seg0;
             bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
-            const bool fast = !t->no_fast && batched && !t->opt.apps_variant && t->opt.sort_by_material && !t->d_albedo && !bp.emit_count;
+            const bool fast = !t->no_fast && batched && t->opt.sort_by_material && !needs_albedo && !bp.emit_count;
             if (first) {
                 if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 1, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
                 else KT(0, hipLaunchKernelGGL((k_bounce<true, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
