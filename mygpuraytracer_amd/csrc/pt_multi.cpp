@@ -10,16 +10,66 @@
 // Parity: every tile equals the oracle run on that tile (stream indices are local to a tile).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi355x_pathtracer.h"
 
 extern "C" void ptx_internal_set_error(const char *msg);
 
+// One host thread per device for the calls that enqueue a lot (render, iterate): a launch set is ~20 launches, i.e. ~0.1 ms of
+// host time, and one thread handing eight devices their sets one after the other would have the last device start 0.7 ms late --
+// more than a short call traces.  The worker owns nothing but the right to call into ITS tracer; errors come back by value.
+struct ptx_multi_worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, finished = true, quit = false;
+    int rc = 0;
+    std::string err;
+    void loop(int device) {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<int()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            const int r = j();
+            const std::string e = r != PTX_OK ? std::string(ptx_last_error()) : std::string();
+            lk.lock();
+            rc = r; err = e; finished = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f); has_job = true; finished = false;
+        cv.notify_all();
+    }
+    int wait(std::string &e) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return finished; });
+        e = err;
+        return rc;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct ptx_multi {
     std::vector<ptx_tracer *> tr;
     std::vector<int> dev;
+    std::vector<std::unique_ptr<ptx_multi_worker>> workers;      // one per device when there are several
     int W = 0, H = 0, tile_rows = 0;
 };
 
@@ -67,12 +117,20 @@ int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *
                 if (e != hipSuccess) (void)hipGetLastError();
             }
         }
+    if (ndevices > 1)
+        for (int i = 0; i < ndevices; i++) {
+            m->workers.emplace_back(new ptx_multi_worker);
+            ptx_multi_worker *w = m->workers.back().get();
+            const int d = devices[i];
+            w->th = std::thread([w, d] { w->loop(d); });
+        }
     *out = m;
     return PTX_OK;
 }
 
 void ptx_multi_destroy(ptx_multi *m) {
     if (!m) return;
+    for (auto &w : m->workers) w->stop();
     for (ptx_tracer *t : m->tr) ptx_destroy(t);
     delete m;
 }
@@ -83,8 +141,21 @@ ptx_tracer *ptx_multi_tracer(ptx_multi *m, int i) { return (m && i >= 0 && i < (
 #define FOR_ALL(call) do { if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi"); for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } while (0)
 int ptx_multi_set_camera(ptx_multi *m, const ptx_camera *camera, int trace_depth) { FOR_ALL(ptx_set_camera(t, camera, trace_depth)); }
 int ptx_multi_reset_image(ptx_multi *m) { FOR_ALL(ptx_reset_image(t)); }
-int ptx_multi_render(ptx_multi *m, int iter_first, int count) { FOR_ALL(ptx_render(t, iter_first, count)); }     /* enqueues on every device, returns */
-int ptx_multi_iterate(ptx_multi *m, int iter) { FOR_ALL(ptx_iterate(t, iter)); }
+// the same call on every device at once, each from that device's own host thread; the first failure (in device order) is reported
+#define PAR_ALL(call) do {                                                                                              \
+        if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi");                                                        \
+        if (m->workers.empty()) { for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } \
+        for (size_t i_ = 0; i_ < m->tr.size(); i_++) { ptx_tracer *t = m->tr[i_]; m->workers[i_]->submit([=]() -> int { return (call); }); } \
+        int first_rc = PTX_OK; std::string first_err;                                                                  \
+        for (size_t i_ = 0; i_ < m->tr.size(); i_++) {                                                                 \
+            std::string e_; const int rc_ = m->workers[i_]->wait(e_);                                                  \
+            if (rc_ != PTX_OK && first_rc == PTX_OK) { first_rc = rc_; first_err = e_; }                               \
+        }                                                                                                              \
+        if (first_rc != PTX_OK) return fail(first_rc, first_err);                                                      \
+        return PTX_OK;                                                                                                 \
+    } while (0)
+int ptx_multi_render(ptx_multi *m, int iter_first, int count) { PAR_ALL(ptx_render(t, iter_first, count)); }     /* enqueues on every device, returns */
+int ptx_multi_iterate(ptx_multi *m, int iter) { PAR_ALL(ptx_iterate(t, iter)); }
 int ptx_multi_set_render_ahead(ptx_multi *m, int on) { FOR_ALL(ptx_set_render_ahead(t, on)); }
 int ptx_multi_synchronize(ptx_multi *m) { FOR_ALL(ptx_synchronize(t)); }
 
