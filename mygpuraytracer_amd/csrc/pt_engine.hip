@@ -1324,7 +1324,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     // so only a launch set that contains iteration 1 needs the general kernel for it)
     const bool needs_albedo = t->d_albedo && iter_first == 1;
     const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && t->opt.sort_by_material &&
-                              !needs_albedo && !t->opt.depth_of_field && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
+                              !needs_albedo && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
                               !t->d_bvh_root;
     // ... the split bounce's kernels are many short ones: 16 workgroups per CU (C5 -2 %); everything else 8 as before
     // (traced ahead of per-call requests: two of the seven slots per CU stay free, so that the caller's own short kernels -- gather,
@@ -1442,7 +1442,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             // the specialised kernel where its assumptions hold (see k_bounce)
-            const bool fast = fast_unsplit && !bp.emit_count;
+            // (depth of field only concerns the kernel that generates the camera rays)
+            const bool fast = fast_unsplit && !bp.emit_count && !(first && t->opt.depth_of_field);
             if (first) {
                 if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
                 else KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
