@@ -46,22 +46,12 @@ PT_HD vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
     return r;
 }
 
-// (experiment, -DPT_KCONST: a binary64 constant formed where it is used -- two scalar moves -- instead of being hoisted out of
-// the kernel's tile loop as a register pair, parked in a vector-register lane and fetched back with two v_readlane per use.
-// Measured 1.5 % SLOWER: the ordering the asm imposes costs more than the lane reads; what does help is -disable-machine-licm.)
-PT_DEV double kd_(double c) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PT_KCONST)
-    asm volatile("" : "+s"(c));
-#endif
-    return c;
-}
-
 // ---- portable libm (same operation sequence as the CPU checker's copy; binary64, one rounding to binary32) ----
 // sin and cos of a float argument, |x| <= 1e5: Cody-Waite reduction by pi/2, Taylor polynomials.
 PT_DEV void sincos_own(float xf, float *s, float *c) {
-    const double INVPIO2 = kd_(0x1.45f306dc9c883p-1);
-    const double PIO2_1 = kd_(0x1.921fb54400000p+0);
-    const double PIO2_1T = kd_(0x1.0b4611a626331p-34);
+    const double INVPIO2 = 0x1.45f306dc9c883p-1;
+    const double PIO2_1 = 0x1.921fb54400000p+0;
+    const double PIO2_1T = 0x1.0b4611a626331p-34;
     double x = (double)xf;
     if (!(x >= -1.0e5 && x <= 1.0e5)) { *s = __builtin_nanf(""); *c = __builtin_nanf(""); return; }
     double y = x * INVPIO2;
@@ -69,21 +59,21 @@ PT_DEV void sincos_own(float xf, float *s, float *c) {
     double kd = (double)k;
     double r = (x - kd * PIO2_1) - kd * PIO2_1T;
     double z = r * r;
-    double ps = kd_(-0x1.ae7f3e733b81fp-41) + z * kd_(0x1.952c77030ad4ap-49);
-    ps = kd_(0x1.6124613a86d09p-33) + z * ps;
-    ps = kd_(-0x1.ae64567f544e4p-26) + z * ps;
-    ps = kd_(0x1.71de3a556c734p-19) + z * ps;
-    ps = kd_(-0x1.a01a01a01a01ap-13) + z * ps;
-    ps = kd_(0x1.1111111111111p-7) + z * ps;
-    ps = kd_(-0x1.5555555555555p-3) + z * ps;
+    double ps = -0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49;
+    ps = 0x1.6124613a86d09p-33 + z * ps;
+    ps = -0x1.ae64567f544e4p-26 + z * ps;
+    ps = 0x1.71de3a556c734p-19 + z * ps;
+    ps = -0x1.a01a01a01a01ap-13 + z * ps;
+    ps = 0x1.1111111111111p-7 + z * ps;
+    ps = -0x1.5555555555555p-3 + z * ps;
     double sr = r + r * (z * ps);
-    double pc = kd_(-0x1.93974a8c07c9dp-37) + z * kd_(0x1.ae7f3e733b81fp-45);
-    pc = kd_(0x1.1eed8eff8d898p-29) + z * pc;
-    pc = kd_(-0x1.27e4fb7789f5cp-22) + z * pc;
-    pc = kd_(0x1.a01a01a01a01ap-16) + z * pc;
-    pc = kd_(-0x1.6c16c16c16c17p-10) + z * pc;
-    pc = kd_(0x1.5555555555555p-5) + z * pc;
-    pc = kd_(-0x1.0000000000000p-1) + z * pc;
+    double pc = -0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45;
+    pc = 0x1.1eed8eff8d898p-29 + z * pc;
+    pc = -0x1.27e4fb7789f5cp-22 + z * pc;
+    pc = 0x1.a01a01a01a01ap-16 + z * pc;
+    pc = -0x1.6c16c16c16c17p-10 + z * pc;
+    pc = 0x1.5555555555555p-5 + z * pc;
+    pc = -0x1.0000000000000p-1 + z * pc;
     double cr = 1.0 + z * pc;
     double sd, cd;
     switch (k & 3) {
@@ -115,41 +105,41 @@ PT_DEV float powf_own(float xf, float yf) {
     uint64_t u = (uint64_t)__double_as_longlong(x);
     int e = (int)((u >> 52) & 0x7ff) - 1023;
     double m = __longlong_as_double((long long)((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
-    if (m > kd_(0x1.6a09e667f3bcdp+0)) { m = m * 0.5; e += 1; }
+    if (m > 0x1.6a09e667f3bcdp+0) { m = m * 0.5; e += 1; }
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
-    double p = kd_(0x1.af286bca1af28p-4) + z * kd_(0x1.8618618618618p-4);
-    p = kd_(0x1.e1e1e1e1e1e1ep-4) + z * p;
-    p = kd_(0x1.1111111111111p-3) + z * p;
-    p = kd_(0x1.3b13b13b13b14p-3) + z * p;
-    p = kd_(0x1.745d1745d1746p-3) + z * p;
-    p = kd_(0x1.c71c71c71c71cp-3) + z * p;
-    p = kd_(0x1.2492492492492p-2) + z * p;
-    p = kd_(0x1.999999999999ap-2) + z * p;
-    p = kd_(0x1.5555555555555p-1) + z * p;
+    double p = 0x1.af286bca1af28p-4 + z * 0x1.8618618618618p-4;
+    p = 0x1.e1e1e1e1e1e1ep-4 + z * p;
+    p = 0x1.1111111111111p-3 + z * p;
+    p = 0x1.3b13b13b13b14p-3 + z * p;
+    p = 0x1.745d1745d1746p-3 + z * p;
+    p = 0x1.c71c71c71c71cp-3 + z * p;
+    p = 0x1.2492492492492p-2 + z * p;
+    p = 0x1.999999999999ap-2 + z * p;
+    p = 0x1.5555555555555p-1 + z * p;
     double logm = 2.0 * s + s * (z * p);
-    const double LN2_HI = kd_(0x1.62e42fee00000p-1), LN2_LO = kd_(0x1.a39ef35793c76p-33);
+    const double LN2_HI = 0x1.62e42fee00000p-1, LN2_LO = 0x1.a39ef35793c76p-33;
     double ed = (double)e;
     double lg = (ed * LN2_HI + logm) + ed * LN2_LO;
     double a = (double)yf * lg;
     if (a > 89.0) return __builtin_inff();
     if (a < -104.0) return 0.0f;
-    double kk = a * kd_(0x1.71547652b82fep+0);
+    double kk = a * 0x1.71547652b82fep+0;
     int k = (int)(kk + (kk >= 0.0 ? 0.5 : -0.5));
     double kd = (double)k;
     double r = (a - kd * LN2_HI) - kd * LN2_LO;
-    double q = kd_(0x1.1eed8eff8d898p-29) + r * kd_(0x1.6124613a86d09p-33);
-    q = kd_(0x1.ae64567f544e4p-26) + r * q;
-    q = kd_(0x1.27e4fb7789f5cp-22) + r * q;
-    q = kd_(0x1.71de3a556c734p-19) + r * q;
-    q = kd_(0x1.a01a01a01a01ap-16) + r * q;
-    q = kd_(0x1.a01a01a01a01ap-13) + r * q;
-    q = kd_(0x1.6c16c16c16c17p-10) + r * q;
-    q = kd_(0x1.1111111111111p-7) + r * q;
-    q = kd_(0x1.5555555555555p-5) + r * q;
-    q = kd_(0x1.5555555555555p-3) + r * q;
-    q = kd_(0x1.0000000000000p-1) + r * q;
+    double q = 0x1.1eed8eff8d898p-29 + r * 0x1.6124613a86d09p-33;
+    q = 0x1.ae64567f544e4p-26 + r * q;
+    q = 0x1.27e4fb7789f5cp-22 + r * q;
+    q = 0x1.71de3a556c734p-19 + r * q;
+    q = 0x1.a01a01a01a01ap-16 + r * q;
+    q = 0x1.a01a01a01a01ap-13 + r * q;
+    q = 0x1.6c16c16c16c17p-10 + r * q;
+    q = 0x1.1111111111111p-7 + r * q;
+    q = 0x1.5555555555555p-5 + r * q;
+    q = 0x1.5555555555555p-3 + r * q;
+    q = 0x1.0000000000000p-1 + r * q;
     double er = 1.0 + (r + r * (r * q));
     double two_k = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
     return (float)(er * two_k);
