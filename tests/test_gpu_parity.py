@@ -1150,11 +1150,13 @@ def test_cpp_veneer_on_several_devices(gpu_product, O, tmp_path):
 
 
 @pytest.mark.parametrize("scene,res,depth,opt", [("cornellObj.txt", (1920, 1080), 8, {}), ("cornellGlass.txt", (640, 360), 12, {}),
-                                                 ("cornell.txt", (400, 400), 8, dict(antialiasing=0)), ("cornellObj.txt", (320, 200), 8, dict(tile_rows=8, tile_rank=1, tile_world=3))])
+                                                 ("cornell.txt", (400, 400), 8, dict(antialiasing=0)), ("cornellObj.txt", (320, 200), 8, dict(tile_rows=8, tile_rank=1, tile_world=3)),
+                                                 ("cornellObj.txt", (480, 270), 8, dict(apps_variant=1)), ("cornellObj.txt", (480, 270), 8, dict(depth_of_field=1))])
 def test_specialised_and_general_bounce_kernels_agree(gpu_product, monkeypatch, scene, res, depth, opt):
     """k_bounce<.., FAST> (options as compile-time constants, chosen per launch where its assumptions hold) against the general
     kernel on the same iterations: same image, same ray counts -- at the bench's full size, with the first-bounce cache (whose
-    filling pass is general, whose later passes are specialised) and on a row tile."""
+    filling pass is general, whose later passes are specialised), on a row tile, with the apps variant (general only for the launch
+    set that holds iteration 1) and with depth of field (general only for the kernel that generates the camera rays)."""
     s = gpu_product.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=depth)
     s.apply_runcuda_camera()
     with gpu_product.Tracer(s, **opt) as A:
