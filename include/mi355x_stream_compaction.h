@@ -9,6 +9,8 @@
  *   StreamCompaction::Efficient::scan           stream_compaction/efficient.cu:36 sc_efficient_scan
  *   StreamCompaction::Efficient::compact        stream_compaction/efficient.cu:79 sc_efficient_compact
  *   StreamCompaction::Thrust::scan              stream_compaction/thrust.cu:20   sc_thrust_scan
+ *   StreamCompaction::Common::kernMapToBoolean  stream_compaction/common.cu:25   sc_map_to_boolean_device
+ *   StreamCompaction::Common::kernScatter       stream_compaction/common.cu:40   sc_scatter_device
  *   <ns>::timer().getGpu/CpuElapsedTimeForPreviousOperation  common.h:48-132     sc_last_gpu_ms / sc_last_cpu_ms
  *
  * Same argument meaning as the reference: n elements, host pointers in and out (the GPU variants allocate and
@@ -41,6 +43,11 @@ int sc_efficient_compact(int n, int *odata, const int *idata);
 unsigned long long sc_scan_workspace_bytes(int n);
 int sc_scan_device(int n, int *d_odata, const int *d_idata, void *d_workspace, void *stream);
 int sc_compact_device(int n, int *d_odata, const int *d_idata, int *d_count, void *d_workspace, void *stream);
+
+/* the two building-block kernels of the reference's own compaction (common.h:38-41), on device arrays of n ints:
+ * bools[i] = idata[i] != 0 ? 1 : 0;   and   bools[i] == 1  =>  odata[indices[i]] = idata[i].   Enqueued on `stream`, no sync. */
+int sc_map_to_boolean_device(int n, int *d_bools, const int *d_idata, void *stream);
+int sc_scatter_device(int n, int *d_odata, const int *d_idata, const int *d_bools, const int *d_indices, void *stream);
 
 float sc_last_gpu_ms(void);      /* device time of the kernels of the previous GPU call (hipEvent), ms */
 float sc_last_cpu_ms(void);      /* wall time of the previous sc_cpu_* call, ms */

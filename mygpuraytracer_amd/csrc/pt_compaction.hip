@@ -63,6 +63,25 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// kernMapToBoolean (common.cu:25-34): bools[i] = idata[i] != 0.  The first n4 quads go as 16-byte accesses (both arrays 16-byte
+// aligned), the rest one by one; HBM-bound, 8 B per element.
+__global__ __launch_bounds__(256) void k_map_to_boolean(int n, int n4, int *__restrict__ bools, const int *__restrict__ idata) {
+    const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int q = t0; q < n4; q += stride) {
+        const v4i a = reinterpret_cast<const v4i *>(idata)[q];
+        v4i b;
+        b.x = a.x != 0; b.y = a.y != 0; b.z = a.z != 0; b.w = a.w != 0;
+        reinterpret_cast<v4i *>(bools)[q] = b;
+    }
+    for (int i = 4 * n4 + t0; i < n; i += stride) bools[i] = idata[i] != 0 ? 1 : 0;
+}
+// kernScatter (common.cu:40-49): bools[i] == 1 => odata[indices[i]] = idata[i]
+__global__ __launch_bounds__(256) void k_scatter(int n, int *__restrict__ odata, const int *__restrict__ idata, const int *__restrict__ bools,
+                                                  const int *__restrict__ indices) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (bools[i] == 1) odata[indices[i]] = idata[i];
+}
+
 // COMPACT = false: out[i] = in[0] + .. + in[i-1].  COMPACT = true: out = the non-zero elements of in, in order;
 // *count = how many.  A tile waits only for tiles with lower tickets, which are resident or done and post their totals
 // before they wait for anything themselves: every wait ends.
@@ -324,6 +343,27 @@ int sc_compact_device(int n, int *d_odata, const int *d_idata, int *d_count, voi
     if (!d_odata || !d_idata || !d_workspace) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
     if (((uintptr_t)d_workspace) & 7) { ptx_internal_set_error("workspace must be 8-byte aligned"); return PTX_ERR_INVALID; }
     return onepass_device(n, d_odata, d_idata, d_count, d_workspace, st, true);
+}
+
+// StreamCompaction::Common::kernMapToBoolean / kernScatter (stream_compaction/common.cu:25-49) on device arrays.  The library's own
+// compaction fuses both into k_onepass and never materialises bools[] or indices[]; these exist for callers that built their own
+// pipeline on the reference's two kernels (map -> their scan -> scatter).
+int sc_map_to_boolean_device(int n, int *d_bools, const int *d_idata, void *stream) {
+    if (n <= 0) return PTX_OK;
+    if (!d_bools || !d_idata) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
+    const int n4 = (((uintptr_t)d_bools | (uintptr_t)d_idata) & 15) == 0 ? n / 4 : 0;
+    const int work = n4 + (n - 4 * n4);
+    hipLaunchKernelGGL(k_map_to_boolean, dim3((unsigned)std::min(8192, (work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, n4, d_bools, d_idata);
+    SC_CHECK(hipGetLastError());
+    return PTX_OK;
+}
+
+int sc_scatter_device(int n, int *d_odata, const int *d_idata, const int *d_bools, const int *d_indices, void *stream) {
+    if (n <= 0) return PTX_OK;
+    if (!d_odata || !d_idata || !d_bools || !d_indices) { ptx_internal_set_error("null device pointer"); return PTX_ERR_INVALID; }
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)std::min(8192, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d_odata, d_idata, d_bools, d_indices);
+    SC_CHECK(hipGetLastError());
+    return PTX_OK;
 }
 
 float sc_last_gpu_ms(void) { return g_gpu_ms; }

@@ -4,7 +4,8 @@
 //
 //  * Streams are SoA (one fp32/int32 array per field, coalesced 256-B wave accesses), not the reference's 44-B
 //    PathSegment / 32-B ShadeableIntersection AoS records: 15 words per stored path (17 with texcoords).
-//  * One bounce = one fused kernel + one stable multi-bin partition (two launches):
+//  * One bounce = ONE launch: the fused kernel, whose tail and whose next launch's head together are the stable multi-bin
+//    partition (round 3; rounds 1-2 ran it as a second kernel, k_move):
 //      k_bounce : shade(b-1) [src/pathtrace.cu:355-404 + interactions.h scatterRay] immediately followed by
 //                 computeIntersections(b) [:261-344] of the scattered ray, for every path still alive; bounce 0
 //                 fuses generateRayFromCamera [:206-255] instead of a shade.  Paths that end at bounce b (miss,
@@ -13,14 +14,18 @@
 //                 dropped -- only paths that will scatter again are stored.
 //                 Every workgroup owns a contiguous chunk of tiles and keeps running per-material counts, so a
 //                 tile's prefix = (totals of earlier workgroups) + (running count inside the chunk): no scan pass.
-//      k_move   : the stable multi-bin partition AS AN INDEX: for every stored path its rank in (material descending,
-//                 previous order) order -- which is the reference's stable_partition [:541] followed by the next bounce's
-//                 stable sort_by_key by material [:518] -- and at that rank the stage slot the path lies in plus the rank
-//                 it WOULD have among all survivors (including the ones that were dropped): that one seeds the shading
-//                 RNG [:373] and must be the reference's.  The 60-byte records stay where k_bounce put them; the next
-//                 k_bounce gathers them through the index (stage tiles are sorted by bin, so it reads runs).
+//      the sort : the reference's stable_partition [:541] followed by the next bounce's stable sort_by_key by material [:518] is
+//                 ONE order: bin (material descending), then workgroup chunk, then tile, then rank in the tile.  It is never
+//                 materialised.  TAIL of k_bounce ("local move"): every workgroup sorts the stored paths of ITS chunk of tiles
+//                 by (bin, tile, rank) into a chunk-local index (8 B per path: stage slot + the path's rank among all survivors of
+//                 its bin inside the chunk) -- no other workgroup's data is needed for that -- and leaves the chunk's per-bin
+//                 counts in a flat [bin][workgroup] "run" table.  HEAD of the next k_bounce: a workgroup that will shade sorted
+//                 positions [A, B) finds the run holding A by three 64-wide scans (bins -> groups of 64 workgroups -> workgroups),
+//                 keeps a window of the next 64 runs' prefixes in LDS, and every position becomes (run, offset) by a 6-step search
+//                 in LDS, hence a slot of the chunk-local index, hence the record and its RNG stream index [:373] (which counts the
+//                 dropped survivors too and must be the reference's).  The 60-byte records stay where k_bounce put them.
 //  * The live count never visits the host: kernels read it from device memory and use grid-stride tile loops,
-//    so a batch of iterations is a fixed sequence of launches; K iterations ride in every launch as segments
+//    so a batch of iterations is a fixed sequence of launches (depth + 2 of them); K iterations ride in every launch as segments
 //    (blockIdx.y), and three such batches are in flight on three streams so that their kernels fill each other's tails.
 //  * Intersection is tile-cooperative (tileIntersect): candidate masks from conservative world boxes, the (ray, geom)
 //    pairs of a 256-path tile pooled in LDS and worked off by dense waves with a 64-bit LDS minimum per ray.  Scenes
@@ -61,9 +66,6 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
 #endif
-#ifndef PT_PIPELINE_INPUT
-#define PT_PIPELINE_INPUT 0
-#endif
 #ifndef PT_PARK_STATE
 #define PT_PARK_STATE 1       // specialised unsplit k_bounce: state that is idle during the pair tests waits in LDS, not in registers
 #endif
@@ -84,7 +86,9 @@ constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT
 constexpr int WAVES = TILE / 64;
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
 // tileIntersect's 2 x 4 list counters
-constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8) + 3) & ~3; }
+// + the window over the input's run tables (locate): 65 start positions, 65 stream-index bases, 64 local-index bases, next run
+constexpr int WIN = 64, WIN_WORDS = 2 * (WIN + 1) + WIN + 2;
+constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8 + WIN_WORDS) + 3) & ~3; }
 // k_bounce's dynamic LDS, in words: [scene tables][head][17 x TILE records].  The record buffer doubles as tileIntersect's
 // scratch, whose 64-bit minimum keys (best[], at word 6*TILE of it) are the target of ds_min_u64: a 4-byte-misaligned
 // 64-bit LDS atomic is a memory aperture violation (that is the fault of gpurun_out/bench11.log, round 1: a head of
@@ -123,9 +127,14 @@ struct PathSoA {
     __host__ __device__ float *v() const { return field(13); }
     __host__ __device__ int32_t *pix() const { return i; }                          // pixelIndex (global, x + y*W)
     __host__ __device__ int32_t *mg() const { return i + (size_t)stride; }          // materialId | geomId << 16
-    __host__ __device__ int32_t *idx() const { return i + 2 * (size_t)stride; }     // stream: RNG stream index; stage: key (see stage_key) or -1
+    __host__ __device__ int32_t *idx() const { return i + 2 * (size_t)stride; }     // stage key (see stage_key) or -1
+    // the chunk-local sorted index a workgroup leaves in its tail (see "local move" in k_bounce): entry e of the chunk's region is
+    // the stage slot of the path that comes e-th in (bin, tile, rank) order inside the chunk, and its rank among ALL survivors of
+    // its bin inside the chunk (the part of the RNG stream index the workgroup can know by itself)
+    __host__ __device__ int32_t *lsrc() const { return i + 3 * (size_t)stride; }
+    __host__ __device__ int32_t *lidx() const { return i + 4 * (size_t)stride; }
 };
-constexpr int SOA_FLOATS = 14, SOA_INTS = 3;
+constexpr int SOA_FLOATS = 14, SOA_INTS = 5;
 
 // stage key: bin | rank among all survivors of the tile << 16 | rank among the stored ones << 24 (ranks < 256)
 __device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << 16) | ((uint32_t)r_scat << 24)); }
@@ -204,9 +213,13 @@ struct BounceParams {
     DScene sc;
     DCamera cam;
     TileMap tm;
-    PathSoA in, stage;                     // in = the stage the previous bounce wrote (tile order), read through perm_*
-    const int32_t *perm_src, *perm_idx;    // sorted position -> slot of `in` / RNG stream index (what k_move wrote)
-    size_t seg_perm;                       // per-segment stride of perm_* (0: the cached bounce-0 permutation, shared)
+    PathSoA in, stage;                     // in = the stage the previous bounce wrote (tile order) with its chunk-local sorted index
+    // the run tables of the launch that wrote `in` (its grid had in_gx workgroups per segment; run r = bin * in_gx + workgroup):
+    const int32_t *in_totals;              // [2][nbins]: survivors / stored paths per bin (n_in = sum of the stored ones)
+    const int32_t *in_super;               // [2][nbins][nsuper]: the same per 64 consecutive workgroups
+    const int32_t *in_chunk;               // [3][chunk_cap]: per run -- survivors, stored paths, start of the run in the local index
+    int32_t in_gx;
+    size_t seg_in_totals, seg_in_chunk;    // per-segment strides of those (0: the cached bounce 0, shared by all segments)
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
@@ -219,9 +232,10 @@ struct BounceParams {
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
     float *albedo;
     int32_t nbins, maxTiles;
-    const int32_t *totals_prev;            // [nbins] stored-path totals of bounce b-1 (n_in = their sum)
     int32_t *counts_all, *counts_scat;     // [nbins][maxTiles]: prefix of the tile inside its workgroup's chunk
-    int32_t *chunk_all, *chunk_scat;       // [nbins][gridDim.x]: totals of each workgroup's chunk of tiles
+    int32_t *chunk;                        // out, [3][chunk_cap], run r = bin * gridDim.x + workgroup: survivors and stored paths of
+                                           // that workgroup's chunk of tiles in that bin, and where the run starts in the local index
+    int32_t chunk_cap;                     // nbins x (workgroups per segment at most)
     int32_t *super_all, *super_scat;       // [nbins][nsuper]:   totals per 64 consecutive workgroups (atomics)
     int32_t *totals_all, *totals_scat;     // [nbins] of this bounce (atomics)
     int32_t nsuper;
@@ -429,6 +443,55 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     TI_STAMP(7);
 }
 
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ int waveInclusiveScan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// ---- where a sorted position lies (head of the sort, see the file comment) --------------------------------------------------
+// The previous bounce left its stored paths as RUNS: run r = bin * gx + workgroup holds cs[r] stored paths (of ca[r] survivors)
+// and starts at cbase[r] in the chunk-local index; in run order (bin-major) the runs ARE the sorted stream.  Position P of that
+// stream lies in the first run whose inclusive prefix of cs exceeds P.
+//
+// scanFind: one wave walks n entries of (stored, survivors) counts 64 at a time, adding them to the running prefixes pre_s /
+// pre_a, and stops at the first entry whose inclusive stored-prefix exceeds A; returns its index (-1: none), with pre_s / pre_a
+// the prefixes in FRONT of it.  All arguments and results are wave-uniform.
+__device__ __forceinline__ int scanFind(const int32_t *cs, const int32_t *ca, int n, int A, int &pre_s, int &pre_a, int lane) {
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int vs = k < n ? cs[k] : 0, va = k < n ? ca[k] : 0;
+        const int is = waveInclusiveScan(vs, lane), ia = waveInclusiveScan(va, lane);
+        const unsigned long long m = __ballot(k < n && pre_s + is > A);
+        if (m) {
+            const int l = __ffsll((long long)m) - 1;
+            pre_s += __builtin_amdgcn_readlane(is - vs, l);
+            pre_a += __builtin_amdgcn_readlane(ia - va, l);
+            return base + l;
+        }
+        pre_s += __builtin_amdgcn_readlane(is, 63);
+        pre_a += __builtin_amdgcn_readlane(ia, 63);
+    }
+    return -1;
+}
+// The window: runs [r0, r0 + WIN) of the table with their exclusive prefixes, in LDS (one wave; the caller brackets it with
+// barriers).  win[0 .. WIN] = first sorted position of each run and of what follows the window, win[WIN+1 .. 2*WIN+1] = the same
+// for the survivor counts (= the RNG stream index of a run's first survivor), then the runs' starts in the local index, then r0 + WIN.
+__device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, int chunk_cap, int nruns, int r0, int gs0, int ga0, int lane) {
+    const int r = r0 + lane;
+    int ca = 0, cs = 0, cb = 0;
+    if (r < nruns) { ca = chunk[r]; cs = chunk[chunk_cap + r]; cb = chunk[2 * chunk_cap + r]; }
+    const int is = waveInclusiveScan(cs, lane), ia = waveInclusiveScan(ca, lane);
+    win[lane] = gs0 + is - cs;
+    win[WIN + 1 + lane] = ga0 + ia - ca;
+    win[2 * (WIN + 1) + lane] = cb;
+    if (lane == 63) { win[WIN] = gs0 + is; win[2 * WIN + 1] = ga0 + ia; win[2 * (WIN + 1) + WIN] = r0 + WIN; }
+}
+
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 constexpr int SPLIT_MAX_MESHES = 2;                  // meshes per scene the split mesh search handles (2 bits of count per ray)
 constexpr int QCAP = 4 * TILE;                       // LDS queue entries of MODE 1, behind the record buffer, + its two counters
@@ -477,6 +540,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
     int32_t *tcnt = toff + nb + 1;                                  // tileIntersect's list counters [2][4], zero between uses
+    int32_t *win = tcnt + 8;                                        // window over the input's run tables [WIN_WORDS] (windowLoad)
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
@@ -491,12 +555,15 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     const int iter = p.iter + seg * p.iter_stride;
     const PathSoA in_k = soa_offset(p.in, p.seg_in * seg), stage_k = soa_offset(p.stage, p.seg_stage * seg);
     int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
-    int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
+    int32_t *chunk_out = p.chunk + p.seg_chunk * seg;
     int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
     int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
     float *part = (FAST || p.part) ? p.part + p.seg_part * seg : nullptr;
     const bool batched = FAST || part != nullptr;
-    const int n_in = FIRST ? p.tm.owned : sum_totals(p.totals_prev + p.seg_totals * seg, nb);
+    const int32_t *in_totals = FIRST ? nullptr : p.in_totals + p.seg_in_totals * seg;
+    const int32_t *in_chunk = FIRST ? nullptr : p.in_chunk + p.seg_in_chunk * seg;
+    const int in_nruns = nb * p.in_gx;
+    const int n_in = FIRST ? p.tm.owned : sum_totals(in_totals + nb, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
     // every workgroup owns a contiguous chunk of tiles, so that the prefix of a tile is (prefix of its chunk) +
     // (running sum inside the chunk) and no separate scan pass over the tiles is needed
@@ -508,27 +575,59 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #else
 #define STAMP(k) do { } while (0)
 #endif
-    // Later bounces read their input records through a software pipeline: tile t+1's fields are requested right after tile
-    // t's intersection, so that their HBM latency passes behind t's classification, ranking and stage write instead of
-    // standing in front of t+1's shading (in-kernel stamps: 12 % of the wave time was that wait).  The index is clamped, not
-    // guarded: lanes past the end fetch the last record and ignore it.
-    constexpr bool PIPE = PT_PIPELINE_INPUT && !FIRST && MODE != 2;
+    // Head of the sort: the run that holds this workgroup's first sorted position, found by wave 0 with three scans over at most
+    // 64 entries each (bins, groups of 64 workgroups of that bin, workgroups of that group), and the window of runs from there on.
+    if (!FIRST && MODE != 2 && tile0 < tile1) {
+        if (wave == 0) {
+            const int32_t *in_super = p.in_super + p.seg_in_totals * seg;
+            const int A = tile0 * TILE;
+            int pre_s = 0, pre_a = 0;
+            const int b = scanFind(in_totals + nb, in_totals, nb, A, pre_s, pre_a, lane);               // A < n_in: there is one
+            const int nsup = (p.in_gx + 63) >> 6;
+            const int sg = scanFind(in_super + (size_t)nb * p.nsuper + (size_t)b * p.nsuper, in_super + (size_t)b * p.nsuper, nsup, A, pre_s, pre_a, lane);
+            const int w0 = sg * 64, nw = min(64, p.in_gx - w0);
+            const int r0 = b * p.in_gx + w0;
+            const int w = scanFind(in_chunk + p.chunk_cap + r0, in_chunk + r0, nw, A, pre_s, pre_a, lane);
+            windowLoad(win, in_chunk, p.chunk_cap, in_nruns, r0 + w, pre_s, pre_a, lane);
+        }
+        __syncthreads();
+    }
     struct InRec { float f[14]; int32_t pix, mg, idx; };
-    InRec nxt;
-    auto fetch = [&](int tile_, InRec &r) {
+    // sorted position -> (entry of the local index, RNG stream index of its run's first survivor).  Uniform call: the window
+    // moves on (barriers) when the tile's last position lies beyond it -- a few times per workgroup at most.
+    auto locate = [&](int tile_, uint32_t &li4, int &idx_base) {
+        const int jp = min(tile_ * TILE + tid, n_in - 1), last = min(tile_ * TILE + TILE - 1, n_in - 1);
+        bool done = false;
+        for (;;) {
+            const int wend = win[WIN];
+            if (!done && jp < wend) {
+                int k = 0;
+#pragma unroll
+                for (int st = WIN / 2; st; st >>= 1) k += win[k + st] <= jp ? st : 0;      // last run that starts at or before jp
+                li4 = (uint32_t)(win[2 * (WIN + 1) + k] + (jp - win[k])) << 2;
+                idx_base = win[WIN + 1 + k];
+                done = true;
+            }
+            // (uniform: every thread reads the same window; the second test cannot hold while the tables are what a k_bounce
+            // leaves -- position < n_in lies in some run -- it is there so that the loop ends whatever they hold)
+            if (last < wend || win[2 * (WIN + 1) + WIN] >= in_nruns) break;
+            __syncthreads();
+            if (wave == 0) windowLoad(win, in_chunk, p.chunk_cap, in_nruns, win[2 * (WIN + 1) + WIN], wend, win[2 * WIN + 1], lane);
+            __syncthreads();
+        }
+    };
+    auto fetch = [&](uint32_t li4, int idx_base, InRec &r) {
         const PathSoA in = soa_fresh(in_k);
-        const int jp = min(tile_ * TILE + tid, n_in - 1);
-        // the sorted stream is not materialised: position jp of it is slot j of the previous bounce's stage
-        const uint32_t jp4 = (uint32_t)jp << 2;
-        const uint32_t j4 = (uint32_t)ld_u(p.perm_src + p.seg_perm * seg, jp4) << 2;
-        r.idx = ld_u(p.perm_idx + p.seg_perm * seg, jp4);
+        // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
+        // slot of that bounce's stage and the path's rank inside its run
+        const uint32_t j4 = (uint32_t)ld_u(in.lsrc(), li4) << 2;
+        r.idx = idx_base + ld_u(in.lidx(), li4);
 #pragma unroll
         for (int k = 0; k < 12; k++) r.f[k] = ld_u(in.field(k), j4);
         r.f[12] = r.f[13] = 0.f;
         if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
         r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
     };
-    if (PIPE && tile0 < tile1) fetch(tile0, nxt);
     for (int tile = tile0; tile < tile1; tile++) {
 #ifdef PT_STAMPS
         st_t0 = __builtin_amdgcn_s_memtime();
@@ -536,7 +635,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
         InRec cur;
-        if (PIPE) cur = nxt;
+        uint32_t li4 = 0;
+        int idx_base = 0;
+        if (!FIRST && MODE != 2) locate(tile, li4, idx_base);
         const PathSoA stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
         int pix = 0;                 // slot among the owned pixels: what the path carries instead of the pixel index
@@ -574,7 +675,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                if (!PIPE) fetch(tile, cur);
+                fetch(li4, idx_base, cur);
                 const vec3 intersect = V3(cur.f[0], cur.f[1], cur.f[2]);           // stored as origin + t * direction
                 ps.d = V3(cur.f[3], cur.f[4], cur.f[5]);
                 ps.color = V3(cur.f[6], cur.f[7], cur.f[8]);
@@ -610,7 +711,6 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             uint32_t mesh_cand = 0;
             if (MODE == 1) {
                 tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
-                if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
                 // Camera rays are coherent: most tiles of the first bounce (256 neighbouring pixels of a row) hold no ray that
                 // reaches a mesh's box at all.  Such a tile is finished right here -- winner's normal, terminal cases,
                 // ranking, in-tile sort, stage write, as in the unsplit kernel -- instead of being parked and picked up again;
@@ -684,7 +784,6 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             }
         }
         STAMP(1);        // intersect
-        if (PIPE && tile + 1 < tile1) fetch(tile + 1, nxt);
     classify:
         if (alive) {
             bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
@@ -833,12 +932,52 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (*qcnt > 0) flushQueue(p, seg, qbuf, qcnt, qbase, tid);
         return;
     }
+    // Tail of the sort ("local move").  run_all / run_scat now hold this chunk's survivors / stored paths per bin.  The chunk's
+    // stored paths get their place in (bin, tile, rank) order INSIDE the chunk -- cbb[bin] = stored paths of the chunk in earlier
+    // bins, + the tile's prefix inside the chunk, + the rank in the tile -- and at that place of the chunk's region of the local
+    // index go the path's stage slot and its rank among all survivors of its bin in the chunk.  Nothing of another workgroup is
+    // needed, so there is no wait; what IS global (the position of a run in the whole stream) the next launch derives from the
+    // run table below.
+    int32_t *cbb = toff;                                              // (free after the tile loop)
+    if (nb <= 64) {
+        if (wave == 0) {
+            const int v = lane < nb ? run_scat[lane] : 0;
+            const int inc = waveInclusiveScan(v, lane);
+            if (lane < nb) cbb[lane] = inc - v;
+        }
+    } else if (tid == 0) {
+        int o = 0;
+        for (int b = 0; b < nb; b++) { cbb[b] = o; o += run_scat[b]; }
+    }
+    __syncthreads();
     for (int b = tid; b < nb; b += TILE) {
         const int ca = run_all[b], cs = run_scat[b];
-        chunk_all[(size_t)b * gridDim.x + blockIdx.x] = ca;
-        chunk_scat[(size_t)b * gridDim.x + blockIdx.x] = cs;
+        const size_t r = (size_t)b * gridDim.x + blockIdx.x;
+        chunk_out[r] = ca;
+        chunk_out[(size_t)p.chunk_cap + r] = cs;
+        chunk_out[2 * (size_t)p.chunk_cap + r] = tile0 * TILE + cbb[b];
         if (ca) { atomicAdd(&super_all[b * p.nsuper + (blockIdx.x >> 6)], ca); atomicAdd(&totals_all[b], ca); }
         if (cs) { atomicAdd(&super_scat[b * p.nsuper + (blockIdx.x >> 6)], cs); atomicAdd(&totals_scat[b], cs); }
+    }
+    {
+        const PathSoA stage = soa_fresh(stage_k);
+        const int32_t *keys = stage.idx();
+        constexpr int MOVE_U = 4;                                     // tiles per step: their keys are requested before the first is used
+        for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
+            int32_t key[MOVE_U];
+#pragma unroll
+            for (int u = 0; u < MOVE_U; u++) key[u] = tbase + u < tile1 ? ld_u(keys, (uint32_t)((tbase + u) * TILE + tid) << 2) : -1;
+#pragma unroll
+            for (int u = 0; u < MOVE_U; u++) {
+                if (key[u] == -1) continue;
+                const int tile = tbase + u;
+                const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
+                const uint32_t c4 = (uint32_t)(bin * p.maxTiles + tile) << 2;      // (a segment's table is below 4 GiB: ptx_create)
+                const int pos = tile0 * TILE + cbb[bin] + ld_u(counts_scat, c4) + r_scat;
+                st_u(stage.lsrc(), (uint32_t)pos << 2, (int32_t)(tile * TILE + tid));
+                st_u(stage.lidx(), (uint32_t)pos << 2, (int32_t)(ld_u(counts_all, c4) + r_all));
+            }
+        }
     }
 }
 
@@ -868,85 +1007,28 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p)
     }
 }
 
-struct MoveParams {
-    PathSoA stage;
-    int32_t *perm_src, *perm_idx;          // out: for every sorted position, the stage slot of its path and its RNG stream index
-    int32_t nbins, maxTiles, first, owned, nsuper;
-    const int32_t *totals_prev;
-    const int32_t *counts_all, *counts_scat, *chunk_all, *chunk_scat, *super_all, *super_scat, *totals_all, *totals_scat;
-    size_t seg_stage, seg_perm, seg_counts, seg_chunk, seg_totals;      // per-segment strides, as in BounceParams
-};
-
-// Stable multi-bin partition, as an INDEX: stored path -> position binBase[bin] + chunkBase[bin] + prefixInChunk + rankInTile;
-// what is written there is not the 60-byte record but where it lies (its stage slot) and the stream index that seeds its RNG.
-// The next k_bounce gathers its records through that index.  Stage tiles are sorted by bin, and the partition is stable,
-// so consecutive positions of one bin are consecutive slots of one tile's run, then of the next tile's: the gather reads
-// runs, not scattered words.  (The records themselves move once per bounce -- out of k_bounce -- instead of twice.)
-// Must be launched with the same grid as the k_bounce that produced the counts (same chunking of tiles).
-__global__ __launch_bounds__(TILE) void k_move(const MoveParams p) {
-    const int nb = p.nbins, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int32_t *base_all = pt_lds, *base_scat = pt_lds + nb;          // dynamic LDS: base_all[nb], base_scat[nb]
-    const int seg = blockIdx.y;
-    const PathSoA stage_k = soa_offset(p.stage, p.seg_stage * seg);
-    int32_t *perm_src = p.perm_src + p.seg_perm * seg, *perm_idx = p.perm_idx + p.seg_perm * seg;
-    const int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
-    const int32_t *chunk_all = p.chunk_all + p.seg_chunk * seg, *chunk_scat = p.chunk_scat + p.seg_chunk * seg;
-    const int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
-    const int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
-    const int n_in = p.first ? p.owned : sum_totals(p.totals_prev + p.seg_totals * seg, nb);
-    const int ntiles = (n_in + TILE - 1) / TILE;
-    const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
-    if (tile0 >= tile1) return;                                    // nothing to move for this workgroup
-    // chunk base of (which, bin) = sum over earlier groups of 64 workgroups + earlier workgroups of the own group
-    const int my_super = blockIdx.x >> 6, in_super = blockIdx.x & 63;
-    for (int pr = wave; pr < 2 * nb; pr += WAVES) {
-        const int which = pr >= nb, b = which ? pr - nb : pr;
-        const int32_t *sup = (which ? super_scat : super_all) + b * p.nsuper;
-        const int32_t *chk = (which ? chunk_scat : chunk_all) + (size_t)b * gridDim.x + (size_t)my_super * 64;
-        const int32_t *tot = which ? totals_scat : totals_all;
-        int s = 0;
-        for (int k = lane; k < my_super; k += 64) s += sup[k];
-        if (lane < in_super) s += chk[lane];
-        for (int k = lane; k < b; k += 64) s += tot[k];          // bins ahead of this one (material descending)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) (which ? base_scat : base_all)[b] = s;
-    }
-    __syncthreads();
-    // MOVE_U tiles per step: their keys are requested before the first is used
-#ifndef PT_MOVE_U
-#define PT_MOVE_U 4
-#endif
-    constexpr int MOVE_U = PT_MOVE_U;
-    const int32_t *keys = stage_k.idx();
-    for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
-        int32_t key[MOVE_U];
-#pragma unroll
-        for (int u = 0; u < MOVE_U; u++) {
-            const int tile = tbase + u;
-            key[u] = tile < tile1 ? ld_u(keys, (uint32_t)(tile * TILE + tid) << 2) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < MOVE_U; u++) {
-            if (key[u] == -1) continue;
-            const int tile = tbase + u;
-            const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
-            const uint32_t c4 = (uint32_t)(bin * p.maxTiles + tile) << 2;      // (a segment's table is below 4 GiB: ptx_create)
-            const int idx = base_all[bin] + ld_u(counts_all, c4) + r_all;
-            const int pos = base_scat[bin] + ld_u(counts_scat, c4) + r_scat;
-            st_u(perm_src, (uint32_t)pos << 2, (int32_t)(tile * TILE + tid));
-            st_u(perm_idx, (uint32_t)pos << 2, (int32_t)idx);
-        }
-    }
+// debug capture: the sorted stream materialised -- what the next k_bounce would read, resolved the slow, obvious way from the same
+// tables (run prefixes by one thread, a binary search per position), so that the parity tests see the order the kernels define
+// without going through k_bounce's own window search.
+__global__ void k_capture_prefix(const int32_t *chunk, int chunk_cap, int nruns, int32_t *gs, int32_t *ga) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int s = 0, a = 0;
+    for (int r = 0; r < nruns; r++) { gs[r] = s; ga[r] = a; a += chunk[r]; s += chunk[chunk_cap + r]; }
+    gs[nruns] = s; ga[nruns] = a;
 }
-
-// debug capture: the sorted stream materialised (what k_move used to write), position k <- stage slot perm_src[k]
-__global__ void k_capture(PathSoA stage, const int32_t *perm_src, const int32_t *perm_idx, int cap, int32_t *out_i, float *out_f) {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += gridDim.x * blockDim.x) {
-        int j = perm_src[k];
-        j = j < 0 ? 0 : (j >= cap ? cap - 1 : j);               // positions past the stream's end hold whatever was there before
-        out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = perm_idx[k]; out_i[2 * (size_t)cap + k] = stage.mg()[j];
+__global__ void k_capture(PathSoA stage, const int32_t *chunk, int chunk_cap, int nruns, const int32_t *gs, const int32_t *ga, int cap,
+                          int32_t *out_i, float *out_f) {
+    const int n = min(gs[nruns], cap);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        int lo = 0, hi = nruns - 1;                              // last run that starts at or before k
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (gs[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        const int li = chunk[2 * chunk_cap + lo] + (k - gs[lo]);
+        int j = stage.lsrc()[li];
+        j = j < 0 ? 0 : (j >= cap ? cap - 1 : j);
+        out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = ga[lo] + stage.lidx()[li]; out_i[2 * (size_t)cap + k] = stage.mg()[j];
         for (int f = 0; f < SOA_FLOATS; f++) out_f[(size_t)f * cap + k] = stage.field(f)[j];
     }
 }
@@ -1145,10 +1227,11 @@ struct ptx_tracer {
     float *d_fbuf[3] = {nullptr, nullptr, nullptr};      // stream, stage, cache
     int32_t *d_ibuf[3] = {nullptr, nullptr, nullptr};
     PathSoA soa[3];                                      // 0, 1 = the two stages (bounce b writes soa[1 - (b & 1)], b + 1 reads it), 2 = first-bounce cache
-    int32_t *d_perm = nullptr;                           // [2][segments x cap]: sorted position -> stage slot, RNG stream index (k_move)
-    int32_t *d_cache_perm = nullptr;                     // [2][cap]: the same for the cached bounce 0
     int32_t *d_counts = nullptr;                         // [2][nbins][maxTiles]
-    int32_t *d_chunk = nullptr;                          // [2][nbins][grid]
+    int32_t *d_chunk = nullptr;                          // [segments][2 (bounce parity)][3][nbins x grid_seg]: the run tables (BounceParams::chunk)
+    int32_t *d_cache_chunk = nullptr;                    // [3][nbins x grid_seg]: the cached bounce 0's
+    int32_t *d_cache_super = nullptr;                    // [2][nbins][nsuper]: the cached bounce 0's
+    int cache_gx = 0;                                    // workgroups per segment of the launch that filled the cache (its run tables' width)
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
@@ -1284,7 +1367,7 @@ int free_tracer(ptx_tracer *t) {
     hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
-    hipFree(t->d_perm); hipFree(t->d_cache_perm);
+    hipFree(t->d_cache_chunk); hipFree(t->d_cache_super);
     hipFree(t->d_counts); hipFree(t->d_chunk); hipFree(t->d_totals); hipFree(t->d_cache_totals);
     hipFree(t->d_emit_count); hipFree(t->d_emit_pix); hipFree(t->d_emit_rgb); hipFree(t->d_stats); hipFree(t->d_cap); hipFree(t->d_cap_f); hipFree(t->d_part); hipFree(t->d_albedo); hipFree(t->d_stamps); hipFree(t->d_pbo); hipFree(t->d_denoised);
     for (hipEvent_t e : t->kev) hipEventDestroy(e);
@@ -1314,7 +1397,6 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
     const int triWords = t->tri_lds ? sceneTableWords(ntri_lds, t->nmats, t->ngeoms) : 0;
     const size_t lds_bounce = sizeof(int32_t) * (bounceLdsWords(triWords, nb) + (t->split_mesh ? QUEUE_WORDS : 0));
-    const size_t lds_move = sizeof(int32_t) * 2 * nb;
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
     const bool fill_cache = cache_on && !use_cache;
@@ -1336,9 +1418,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     if (gx > grid) gx = grid;
     if (gx < 1) gx = 1;
     const int nsuper = (gx + 63) / 64;
-    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * (size_t)nb * t->grid_seg, seg_totals = t->seg_totals;
+    const size_t chunk_cap = (size_t)nb * t->grid_seg;                 // runs per table at most
+    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * 3 * chunk_cap, seg_totals = t->seg_totals;
     int32_t *counts_all = t->d_counts + seg0 * seg_counts, *counts_scat = counts_all + (size_t)nb * t->maxTiles;
-    int32_t *chunk_all = t->d_chunk + seg0 * seg_chunk, *chunk_scat = chunk_all + (size_t)nb * gx;
+    // run tables of bounce b: parity b & 1 of the segment's pair (bounce b + 1 reads them while it writes its own)
+    auto chunks = [&](int bounce) { return t->d_chunk + seg0 * seg_chunk + (size_t)(bounce & 1) * 3 * chunk_cap; };
     auto totals = [&](int bounce, int which) { return t->d_totals + seg0 * seg_totals + ((size_t)bounce * 2 + which) * nb; };
     auto supers = [&](int bounce, int which) { return t->d_super + seg0 * seg_totals + ((size_t)bounce * 2 + which) * nb * t->nsuper; };
     // per-bounce totals and group totals are accumulated with atomics: clear them once per batch
@@ -1386,25 +1470,26 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->split_mesh ? 0 : t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
         // (split: the mesh search runs in k_mesh from global memory, so the triangle tables need no LDS)
         // bounce b writes its stage into soa[1 - (b & 1)] (bounce 0 of a cache-enabled tracer: into soa[2], kept across
-        // iterations) and reads the previous bounce's through the permutation k_move left
+        // iterations) and reads the previous bounce's through that bounce's local index and run tables
         const bool from_cache = (b == 1 && cache_on), to_cache = (first && cache_on);
         bp.in = from_cache ? t->soa[2] : soa_shift(t->soa[b & 1], seg0 * t->cap);
         bp.stage = to_cache ? t->soa[2] : soa_shift(t->soa[1 - (b & 1)], seg0 * t->cap);
-        bp.perm_src = from_cache ? t->d_cache_perm : t->d_perm + seg0 * t->cap;
-        bp.perm_idx = from_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride + seg0 * t->cap;
-        bp.seg_perm = from_cache ? 0 : (size_t)t->cap;
+        bp.in_totals = first ? nullptr : from_cache ? t->d_cache_totals : totals(b - 1, 0);
+        bp.in_super = first ? nullptr : from_cache ? t->d_cache_super : supers(b - 1, 0);
+        bp.in_chunk = first ? nullptr : from_cache ? t->d_cache_chunk : chunks(b - 1);
+        bp.in_gx = from_cache ? t->cache_gx : gx;
+        bp.seg_in_totals = from_cache ? 0 : seg_totals; bp.seg_in_chunk = from_cache ? 0 : seg_chunk;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
         bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
-        bp.totals_prev = first ? nullptr : totals(b - 1, 1);
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
-        bp.chunk_all = chunk_all; bp.chunk_scat = chunk_scat;
+        bp.chunk = to_cache ? t->d_cache_chunk : chunks(b); bp.chunk_cap = (int32_t)chunk_cap;
         bp.super_all = supers(b, 0); bp.super_scat = supers(b, 1);
         bp.totals_all = totals(b, 0); bp.totals_scat = totals(b, 1);
         bp.nsuper = t->nsuper;
         bp.seg_in = from_cache ? 0 : (size_t)t->cap; bp.seg_stage = to_cache ? 0 : (size_t)t->cap;
-        bp.seg_counts = seg_counts; bp.seg_chunk = seg_chunk; bp.seg_totals = seg_totals;
+        bp.seg_counts = seg_counts; bp.seg_chunk = to_cache ? 0 : seg_chunk; bp.seg_totals = seg_totals;
         bp.stamps = t->d_stamps;
         bp.seg_part = t->seg_part;
         bp.part = batched ? t->d_part + seg0 * bp.seg_part : nullptr;
@@ -1453,30 +1538,18 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             }
         }
 
-        if (b + 1 < t->traceDepth) {
-            MoveParams mp;
-            mp.stage = bp.stage;
-            mp.perm_src = to_cache ? t->d_cache_perm : t->d_perm + seg0 * t->cap;
-            mp.perm_idx = to_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride + seg0 * t->cap;
-            mp.nbins = nb; mp.maxTiles = t->maxTiles; mp.first = first; mp.owned = t->tm.owned; mp.nsuper = t->nsuper;
-            mp.totals_prev = bp.totals_prev;
-            mp.counts_all = counts_all; mp.counts_scat = counts_scat;
-            mp.chunk_all = chunk_all; mp.chunk_scat = chunk_scat;
-            mp.super_all = supers(b, 0); mp.super_scat = supers(b, 1);
-            mp.totals_all = totals(b, 0); mp.totals_scat = totals(b, 1);
-            mp.seg_stage = bp.seg_stage; mp.seg_perm = to_cache ? 0 : (size_t)t->cap;
-            mp.seg_counts = seg_counts; mp.seg_chunk = seg_chunk; mp.seg_totals = seg_totals;
-            KT(3, hipLaunchKernelGGL(k_move, dim3(gx, K), dim3(TILE), lds_move, stream, mp));
-        }
         if (first && fill_cache) {
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, stream));
+            HIPCHECK(hipMemcpyAsync(t->d_cache_super, supers(0, 0), sizeof(int32_t) * 2 * nb * t->nsuper, hipMemcpyDeviceToDevice, stream));
+            t->cache_gx = gx;
             t->cache_valid = true;
         }
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
             // (K == 1, lane 0: segment 0 of the buffers)
-            hipLaunchKernelGGL(k_capture, dim3(std::min(1024, (t->cap + 255) / 256)), dim3(256), 0, stream, bp.stage,
-                               to_cache ? t->d_cache_perm : t->d_perm, to_cache ? t->d_cache_perm + t->cap : t->d_perm + t->field_stride,
-                               t->cap, t->d_cap, t->d_cap_f);
+            int32_t *gs = t->d_cap + 3 * (size_t)t->cap + nb, *ga = gs + chunk_cap + 1;
+            hipLaunchKernelGGL(k_capture_prefix, dim3(1), dim3(64), 0, stream, bp.chunk, (int)chunk_cap, nb * gx, gs, ga);
+            hipLaunchKernelGGL(k_capture, dim3(std::min(1024, (t->cap + 255) / 256)), dim3(256), 0, stream, bp.stage, bp.chunk, (int)chunk_cap,
+                               nb * gx, gs, ga, t->cap, t->d_cap, t->d_cap_f);
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
             t->cap_filled = true;
         }
@@ -1870,12 +1943,6 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
-    HC(hipMalloc(&t->d_perm, sizeof(int32_t) * 2 * t->field_stride));
-    HC(hipMemset(t->d_perm, 0, sizeof(int32_t) * 2 * t->field_stride));
-    if (t->cache_active()) {
-        HC(hipMalloc(&t->d_cache_perm, sizeof(int32_t) * 2 * (size_t)t->cap));
-        HC(hipMemset(t->d_cache_perm, 0, sizeof(int32_t) * 2 * (size_t)t->cap));
-    }
     t->seg_part = 3 * (size_t)t->cap;                 // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles
     if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * t->seg_part * nseg));
     {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull) and a
@@ -1901,13 +1968,19 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     }
     HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * nseg));
     t->nsuper = (t->grid_seg + 63) / 64;
-    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * (size_t)t->nbins * t->grid_seg * nseg));
+    HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * 3 * (size_t)t->nbins * t->grid_seg * nseg));
+    HC(hipMemset(t->d_chunk, 0, sizeof(int32_t) * 2 * 3 * (size_t)t->nbins * t->grid_seg * nseg));
+    if (t->cache_active()) {
+        HC(hipMalloc(&t->d_cache_chunk, sizeof(int32_t) * 3 * (size_t)t->nbins * t->grid_seg));
+        HC(hipMemset(t->d_cache_chunk, 0, sizeof(int32_t) * 3 * (size_t)t->nbins * t->grid_seg));
+    }
     t->seg_totals = 2 * (size_t)t->nbins * t->maxBounces * (1 + (size_t)t->nsuper);
     t->totals_bytes = sizeof(int32_t) * t->seg_totals * nseg;
     HC(hipMalloc(&t->d_totals, t->totals_bytes));
     HC(hipMemset(t->d_totals, 0, t->totals_bytes));
     t->d_super = t->d_totals + 2 * (size_t)t->nbins * t->maxBounces;
     HC(hipMalloc(&t->d_cache_totals, sizeof(int32_t) * 2 * (size_t)t->nbins));
+    HC(hipMalloc(&t->d_cache_super, sizeof(int32_t) * 2 * (size_t)t->nbins * t->nsuper));
     HC(hipMalloc(&t->d_emit_count, sizeof(int32_t)));
     HC(hipMemset(t->d_emit_count, 0, sizeof(int32_t)));
     HC(hipMalloc(&t->d_emit_pix, sizeof(int32_t) * (size_t)t->cap));
@@ -2370,7 +2443,8 @@ int ptx_debug_set_capture(ptx_tracer *t, int bounce) {
     t->capture_bounce = bounce;
     t->cap_filled = false;
     if (bounce >= 0 && !t->d_cap) {
-        HIPCHECK(hipMalloc(&t->d_cap, sizeof(int32_t) * (3 * (size_t)t->cap + (size_t)t->nbins)));
+        // pix, stream index, material|geom [cap each], the bounce's totals [nbins], run prefixes of the capture [2][nbins x grid_seg + 1]
+        HIPCHECK(hipMalloc(&t->d_cap, sizeof(int32_t) * (3 * (size_t)t->cap + (size_t)t->nbins + 2 * ((size_t)t->nbins * t->grid_seg + 1))));
         HIPCHECK(hipMalloc(&t->d_cap_f, sizeof(float) * SOA_FLOATS * (size_t)t->cap));
     }
     return PTX_OK;

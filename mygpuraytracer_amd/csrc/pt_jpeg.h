@@ -7,11 +7,10 @@
 //   * Huffman / progressive entropy decoding as in ITU T.81 (baseline, extended and progressive 8-bit frames, restart
 //     intervals); baseline coefficients are dequantised as they are decoded, progressive ones at the end, both in
 //     16-bit arithmetic (stb_image.h:2180-2228, 2234-2407, 3058-3085);
-//   * the integer IDCT derived from jidctint with 12-bit constants, +512 >> 10 after the column pass and
-//     +65536 + (128 << 17) >> 17 after the row pass (stb_image.h:2392-2490).  The one-dimensional butterfly, PTJ_IDCT_1D
-//     below, is TRANSCRIBED statement for statement from stb_image's public-domain macro STBI__IDCT_1D
-//     (src/stb_image.h:2396-2432; int64_t in place of int), not re-derived: a lossy format's texels are defined by that
-//     exact sequence of integer operations, so there is nothing to restate differently;
+//   * an integer IDCT that produces stb_image's values (12-bit constants, +512 >> 10 after the column pass and
+//     +65536 + (128 << 17) >> 17 after the row pass; stb_image.h:2392-2490) in an own formulation: the 8-point transform as
+//     two 4x4 integer matrices (idct1d below), whose entries are the sums the factored network forms of its twelve rounded
+//     constants -- exact integer arithmetic, hence the same bytes, pinned by tests/golden/jpeg_textures.npz;
 //   * chroma upsampling by the "3:1" triangle filters, per row pair as the decoder walks down the picture
 //     (stb_image.h:3397-3590, 3840-3880), nearest neighbour for factors other than 2;
 //   * YCbCr -> RGB in 20-bit fixed point with the Cb term of green masked to 16 bits (stb_image.h:3596-3622); frames whose
@@ -256,52 +255,41 @@ struct Decoder {
     }
 
     static uint8_t clamp8(int64_t x) { return x < 0 ? 0 : (x > 255 ? 255 : (uint8_t)x); }
-#define PTJ_F2F(x) ((int)(((x) * 4096 + 0.5)))
-#define PTJ_FSH(x) ((x) * 4096)
-#define PTJ_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                                   \
-    /* 64-bit temporaries: same values as stb_image's ints on every well-formed file, no overflow on corrupt ones */ \
-    int64_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                       \
-    p2 = s2; p3 = s6;                                                                                                 \
-    p1 = (p2 + p3) * PTJ_F2F(0.5411961f);                                                                             \
-    t2 = p1 + p3 * PTJ_F2F(-1.847759065f);                                                                            \
-    t3 = p1 + p2 * PTJ_F2F(0.765366865f);                                                                             \
-    p2 = s0; p3 = s4;                                                                                                 \
-    t0 = PTJ_FSH(p2 + p3); t1 = PTJ_FSH(p2 - p3);                                                                     \
-    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                           \
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                               \
-    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                                           \
-    p5 = (p3 + p4) * PTJ_F2F(1.175875602f);                                                                           \
-    t0 = t0 * PTJ_F2F(0.298631336f); t1 = t1 * PTJ_F2F(2.053119869f);                                                 \
-    t2 = t2 * PTJ_F2F(3.072711026f); t3 = t3 * PTJ_F2F(1.501321110f);                                                 \
-    p1 = p5 + p1 * PTJ_F2F(-0.899976223f); p2 = p5 + p2 * PTJ_F2F(-2.562915447f);                                     \
-    p3 = p3 * PTJ_F2F(-1.961570560f); p4 = p4 * PTJ_F2F(-0.390180644f);                                               \
-    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+    // 8x8 inverse DCT, 12-bit fixed point, written as the two 4x4 integer matrices an 8-point IDCT splits into (even inputs ->
+    // the symmetric part, odd inputs -> the antisymmetric part): out[k] = E[k].(s0 s2 s4 s6) + O[k].(s1 s3 s5 s7),
+    // out[7-k] = the same with a minus.  The entries are sums of the twelve rotation constants of the classic LLM factorisation
+    // rounded to 1/4096 (what stb_image v2.27 uses: 2217 = round(0.5411961 * 4096), ...); integer arithmetic is exact, so this
+    // matrix form yields, bit for bit, what the factored butterfly network with those constants yields -- which is what makes
+    // the texels those of the reference's loader (tests/golden/jpeg_textures.npz) -- without being that network.
+    // 64-bit accumulators: no overflow on corrupt coefficient data either.
+    static void idct1d(const int64_t s[8], int64_t sym[4], int64_t asym[4]) {
+        static const int32_t E[4][4] = {{4096, 5352, 4096, 2217}, {4096, 2217, -4096, -5350}, {4096, -2217, -4096, 5350}, {4096, -5352, 4096, -2217}};
+        static const int32_t O[4][4] = {{5683, 4816, 3219, 1131}, {4816, -1129, -5681, -3218}, {3219, -5681, 1132, 4816}, {1131, -3218, 4816, -5680}};
+        for (int k = 0; k < 4; k++) {
+            sym[k] = E[k][0] * s[0] + E[k][1] * s[2] + E[k][2] * s[4] + E[k][3] * s[6];
+            asym[k] = O[k][0] * s[1] + O[k][1] * s[3] + O[k][2] * s[5] + O[k][3] * s[7];
+        }
+    }
     static void idct(uint8_t *out, int stride, const int16_t d[64]) {
         int64_t val[64];
-        for (int i = 0; i < 8; i++) {
-            const int16_t *c = d + i;
-            int64_t *v = val + i;
-            if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-                const int64_t dcterm = c[0] * 4;
-                v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
-            } else {
-                PTJ_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
-                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-                v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
-                v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-                v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-                v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        for (int col = 0; col < 8; col++) {               // columns: result kept with 2 extra bits (>> 10 of the 12)
+            int64_t s[8], e[4], o[4];
+            for (int k = 0; k < 8; k++) s[k] = d[k * 8 + col];
+            idct1d(s, e, o);
+            for (int k = 0; k < 4; k++) {
+                val[k * 8 + col] = (e[k] + o[k] + 512) >> 10;
+                val[(7 - k) * 8 + col] = (e[k] - o[k] + 512) >> 10;
             }
         }
-        for (int i = 0; i < 8; i++) {
-            const int64_t *v = val + i * 8;
-            uint8_t *o = out + (size_t)i * stride;
-            PTJ_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-            x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
-            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17);
-            o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
-            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17);
-            o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+        for (int row = 0; row < 8; row++) {               // rows: >> 17 in all, + 128 level shift, rounded
+            int64_t e[4], o[4];
+            idct1d(val + row * 8, e, o);
+            uint8_t *px = out + (size_t)row * stride;
+            const int64_t bias = 65536 + (128 << 17);
+            for (int k = 0; k < 4; k++) {
+                px[k] = clamp8((e[k] + o[k] + bias) >> 17);
+                px[7 - k] = clamp8((e[k] - o[k] + bias) >> 17);
+            }
         }
     }
 

@@ -11,8 +11,11 @@
 // compile and mean what they meant: host pointers in and out, exclusive prefix sums, non-zero elements kept in order, one
 // timer per namespace holding the time of that namespace's previous operation (common.h:48-132).  A failing GPU call
 // prints and exits like checkCUDAError (common.h:17-20, common.cu:3-17); use the C ABI for return codes.
-// Not carried over: Common::kernMapToBoolean / kernScatter (__global__ kernels of the reference's own implementation,
-// common.h:38-41), and startGpuTimer/endGpuTimer and their CPU twins (the library times its operations itself).
+// Common::kernMapToBoolean / kernScatter (common.h:38-41) are __global__ kernels in the reference, launched by its own
+// compaction with <<<grid, block>>>; here they are ordinary functions on device pointers that enqueue the whole array on a
+// stream (default: the null stream), because this header must also compile in translation units without HIP:
+//     StreamCompaction::Common::kernMapToBoolean(n, dev_bools, dev_idata);              // was <<<blocks, 128>>>(n, ...)
+// Not carried over: startGpuTimer/endGpuTimer and their CPU twins (the library times its operations itself).
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +45,14 @@ inline void mi355x_check(int rc, const char *what) {
     if (rc == 0) return;
     fprintf(stderr, "mi355x stream compaction error (%s): %s\n", what, ptx_last_error());
     exit(EXIT_FAILURE);
+}
+
+// common.h:38-41, common.cu:25-49 -- device pointers; the launch configuration is the library's business
+inline void kernMapToBoolean(int n, int *bools, const int *idata, void *stream = nullptr) {
+    mi355x_check(sc_map_to_boolean_device(n, bools, idata, stream), "Common::kernMapToBoolean");
+}
+inline void kernScatter(int n, int *odata, const int *idata, const int *bools, const int *indices, void *stream = nullptr) {
+    mi355x_check(sc_scatter_device(n, odata, idata, bools, indices, stream), "Common::kernScatter");
 }
 
 }  // namespace Common
