@@ -198,6 +198,8 @@ def load_library():
     L.sc_scan_workspace_bytes.restype, L.sc_scan_workspace_bytes.argtypes = C.c_ulonglong, [i]
     L.sc_scan_device.restype, L.sc_scan_device.argtypes = i, [i, vp, vp, vp, vp]
     L.sc_compact_device.restype, L.sc_compact_device.argtypes = i, [i, vp, vp, vp, vp, vp]
+    L.sc_map_to_boolean_device.restype, L.sc_map_to_boolean_device.argtypes = i, [i, vp, vp, vp]
+    L.sc_scatter_device.restype, L.sc_scatter_device.argtypes = i, [i, vp, vp, vp, vp, vp]
     L.sc_last_gpu_ms.restype = f
     L.sc_last_cpu_ms.restype = f
     L.sc_ilog2.restype, L.sc_ilog2.argtypes = i, [i]
@@ -671,6 +673,13 @@ class StreamCompaction:
 
     def compact_device(self, n, d_out, d_in, d_count, d_workspace, stream=0):
         _check(self.lib.sc_compact_device(int(n), d_out, d_in, d_count, d_workspace, stream), "sc_compact_device")
+
+    # StreamCompaction::Common::kernMapToBoolean / kernScatter (stream_compaction/common.cu:25-49) on device arrays
+    def map_to_boolean_device(self, n, d_bools, d_in, stream=0):
+        _check(self.lib.sc_map_to_boolean_device(int(n), d_bools, d_in, stream), "sc_map_to_boolean_device")
+
+    def scatter_device(self, n, d_out, d_in, d_bools, d_indices, stream=0):
+        _check(self.lib.sc_scatter_device(int(n), d_out, d_in, d_bools, d_indices, stream), "sc_scatter_device")
 
     def last_gpu_ms(self):
         return float(self.lib.sc_last_gpu_ms())

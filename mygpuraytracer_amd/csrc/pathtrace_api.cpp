@@ -13,6 +13,7 @@ namespace {
 Scene *hst_scene = nullptr;          // borrowed, must outlive pathtraceFree (src/pathtrace.cu:91,102)
 ptx_tracer *g_tracer = nullptr;
 ptx_multi *g_multi = nullptr;        // != NULL: several devices (pathtraceDevices()); g_tracer is then device 0's tracer
+bool g_albedo_read = false;          // several devices, apps variant: state.albedo holds the merged AOV of iteration 1
 void *g_pinned[3] = {nullptr, nullptr, nullptr};      // state.image / state.albedo page-locked for the per-iteration read-back
 ptx_options g_options;
 bool g_options_init = false;
@@ -113,6 +114,7 @@ float PerformanceTimer::getGpuElapsedTimeForPreviousOperation() {
 
 void pathtraceInit(Scene *scene) {
     hst_scene = scene;
+    g_albedo_read = false;
     const std::vector<int> &devs = pathtraceDevices();
     if (devs.size() > 1) {
         // the C ABI's multi-device layer takes the loaded scene: hand it the caller's camera and depth first
@@ -155,7 +157,12 @@ void pathtrace(void *pbo, int frame, int iter) {
         check(ptx_multi_iterate(g_multi, iter), "pathtrace");
         check(ptx_multi_read_image(g_multi, &hst_scene->state.image[0].x), "image readback");      // assemble + :555-556
         if (!apps) check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");             // from the assembled frame
-        if (apps) check(ptx_multi_read_albedo(g_multi, &hst_scene->state.albedo[0].x), "albedo readback");
+        // the AOV is written by iteration 1 alone (apps/src/pathtrace.cu:412-462): merged from the devices once, when it is new,
+        // not n full-frame reads and a host merge per call
+        if (apps && (iter == 1 || !g_albedo_read)) {
+            check(ptx_multi_read_albedo(g_multi, &hst_scene->state.albedo[0].x), "albedo readback");
+            g_albedo_read = true;
+        }
         check(ptx_synchronize(g_tracer), "pathtrace");
         return;
     }

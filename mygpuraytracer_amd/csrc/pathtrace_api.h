@@ -16,9 +16,13 @@
 #include "../../include/mi355x_pathtracer.h"
 
 // The pbo arguments are device pointers to uchar4 exactly as in the reference (the mapped GL buffer of src/main.cpp:131-135).
-// They are declared void* so that this header compiles -- and the calls link -- whether or not the caller's translation unit
-// has HIP's vector types (hip_runtime.h makes uchar4 a typedef of a class template, which can neither be forward-declared
-// nor be mangled the same way from a file without it); `pathtrace(pbo_dptr, frame, iteration)` converts implicitly.
+// The exported functions take void* so that this header compiles -- and the calls link -- whether or not the caller's
+// translation unit has HIP's vector types (hip_runtime.h makes uchar4 a typedef of a class template, which can neither be
+// forward-declared nor be mangled the same way from a file without it).  A translation unit that HAS them (it included
+// hip_runtime.h / hip_vector_types.h before this header, as src/main.cpp's includes do through pathtrace.h's
+// <cuda_runtime.h> counterpart) also gets the reference's exact signatures, `pathtrace(uchar4 *, int, int)` and
+// `sendToGPU(uchar4 *, int)`, as inline overloads at the end of this header: taking the function's address with the
+// reference's type, or overload resolution against other pathtrace() functions, then behaves as with src/pathtrace.h:9.
 
 namespace mi355x {
 struct vec3 { float x, y, z; };
@@ -83,3 +87,8 @@ void pathtraceFree();                                   // src/pathtrace.h:8
 void pathtrace(void *pbo, int frame, int iteration);    // src/pathtrace.h:9 (uchar4 *pbo); pbo may be NULL (no preview)
 void sendToGPU(void *pbo, int iter);                    // apps/src/pathtrace.h:10 (uchar4 *pbo): state.output -> 8-bit preview in the device pbo
 ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state (device 0's with several devices)
+
+#if defined(HIP_INCLUDE_HIP_HIP_VECTOR_TYPES_H) || defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H)      // uchar4 is known here: the reference's own signatures (src/pathtrace.h:9, apps/src/pathtrace.h:10)
+inline void pathtrace(uchar4 *pbo, int frame, int iteration) { pathtrace(static_cast<void *>(pbo), frame, iteration); }
+inline void sendToGPU(uchar4 *pbo, int iter) { sendToGPU(static_cast<void *>(pbo), iter); }
+#endif

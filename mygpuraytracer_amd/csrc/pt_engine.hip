@@ -1243,6 +1243,8 @@ struct ptx_tracer {
     uint32_t bump_bits = 0;
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
     bool no_fast = false;                                // PTX_DEBUG_NO_FAST: always the general k_bounce (A/B timing, tests of both variants)
+    bool force_fast = false;                             // PTX_DEBUG_FORCE_FAST: ask for the specialised variant at every launch (refused
+                                                         // with PTX_ERR_INVALID where its preconditions do not hold; tests only)
     unsigned long long *d_keys = nullptr; uint32_t *d_items = nullptr; int32_t *d_item_count = nullptr;
     int32_t *d_tile_done = nullptr;                      // split first bounce: [segments][maxTiles], see BounceParams::tile_done
     size_t seg_items = 0;
@@ -1384,6 +1386,56 @@ int free_tracer(ptx_tracer *t) {
     return PTX_OK;
 }
 
+// The specialised variants k_bounce<., ., FAST> hard-wire option values inside the kernel (sort = 1, no cache fill, no albedo, per-
+// iteration radiance buffers; the unsplit one also: all scene tables in LDS, no texture, no bump map, no BVH, no depth of field).
+// Run outside them they index tables the host sized for OTHER values: with sort_by_material = 0 the host has ONE bin, the kernel
+// computes bin = nmats - 1 - material and writes past every per-bin table in LDS and in global memory -- that was round 2's fault
+// (gpurun_out/quick_S1.log: an A/B build that took the variant unconditionally; wrong frames on the cache-filling pass and with
+// depth of field, then "Memory access fault" on cornellObj with sort_by_material = 0).  So there is ONE predicate, used by every
+// launch site: it names the first assumption that does not hold (nullptr: all hold), and launch_bounce refuses -- PTX_ERR_INVALID,
+// nothing is launched -- when the variant is asked for regardless (PTX_DEBUG_FORCE_FAST, tests only).
+const char *fast_violation(const ptx_tracer *t, int mode, bool first, bool needs_albedo, const BounceParams &bp) {
+    if (!bp.part) return "no per-iteration radiance buffers (part == NULL): the variant stores, it never adds to the image";
+    if (!bp.sort || bp.nbins != std::max(t->nmats, 1)) return "sort_by_material = 0: the per-bin tables hold one bin";
+    if (bp.emit_count) return "the cache-filling pass (emit_count != NULL) records bounce-0 light hits";
+    if (needs_albedo) return "the launch set contains iteration 1 of the apps variant (albedo AOV)";
+    if (!bp.sc.cull || !bp.sc.tri_lds) return "candidate masks or LDS scene tables are off";
+    if (mode == 0) {
+        if (t->split_mesh) return "the scene takes the split mesh search";
+        if (first && bp.dof) return "depth of field on the camera-ray bounce";
+        if (bp.uses_uv) return "textured scene";
+        if (bp.sc.bump_bits) return "bump-mapped mesh";
+        if (bp.sc.ntri_lds != bp.sc.ntri) return "triangle tables not staged in LDS";
+        if (bp.sc.bvh_root) return "mesh with a BVH";
+    } else if (!t->split_mesh || !bp.keys || !bp.items || !bp.item_count) return "not the split mesh search";
+    return nullptr;
+}
+
+template <bool FIRST, int MODE>
+void launch_bounce_variant(bool fast, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
+    if (fast) hipLaunchKernelGGL((k_bounce<FIRST, MODE, true>), grid, dim3(TILE), lds, stream, bp);
+    else hipLaunchKernelGGL((k_bounce<FIRST, MODE, false>), grid, dim3(TILE), lds, stream, bp);
+}
+// the one launch site of k_bounce: picks the variant by the predicate above
+int launch_bounce(const ptx_tracer *t, bool first, int mode, bool needs_albedo, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
+    const char *why = fast_violation(t, mode, first, needs_albedo, bp);
+    bool fast = !t->no_fast && !why;
+    if (t->force_fast) {
+        if (why) return set_error(PTX_ERR_INVALID, std::string("specialised k_bounce requested outside its preconditions: ") + why);
+        fast = true;
+    }
+    if (first) {
+        if (mode == 0) launch_bounce_variant<true, 0>(fast, grid, lds, stream, bp);
+        else if (mode == 1) launch_bounce_variant<true, 1>(fast, grid, lds, stream, bp);
+        else launch_bounce_variant<true, 2>(fast, grid, lds, stream, bp);
+    } else {
+        if (mode == 0) launch_bounce_variant<false, 0>(fast, grid, lds, stream, bp);
+        else if (mode == 1) launch_bounce_variant<false, 1>(fast, grid, lds, stream, bp);
+        else launch_bounce_variant<false, 2>(fast, grid, lds, stream, bp);
+    }
+    return PTX_OK;
+}
+
 // Enqueues K iterations (iter_first, iter_first + stride, ...) as K segments of every launch: blockIdx.y picks
 // the segment, each segment is an independent stream with its own buffers, so the launches carry K times the work
 // (what keeps a 1/8-frame tile of a multi-GPU run, or the thin late bounces, from being launch- and tail-bound).
@@ -1405,6 +1457,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     // (the apps variant's x PI at the deposit stays a run-time value in every kernel; its albedo AOV is written by iteration 1 alone,
     // so only a launch set that contains iteration 1 needs the general kernel for it)
     const bool needs_albedo = t->d_albedo && iter_first == 1;
+    // (only the grid size depends on this estimate; what is launched is decided per launch by fast_violation)
     const bool fast_unsplit = !t->split_mesh && !t->no_fast && batched && !t->uses_uv && t->opt.sort_by_material &&
                               !needs_albedo && t->cull && t->tri_lds && t->bump_bits == 0 && t->ntri_lds == t->ntri &&
                               !t->d_bvh_root;
@@ -1501,14 +1554,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.item_count = t->d_item_count + seg0;
             bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
-            const bool fast = !t->no_fast && batched && t->opt.sort_by_material && !needs_albedo && !bp.emit_count;
-            if (first) {
-                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 1, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(0, hipLaunchKernelGGL((k_bounce<true, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            } else {
-                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 1, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(1, hipLaunchKernelGGL((k_bounce<false, 1>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            }
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
             MeshParams mq;
             mq.sc = t->scene();                                   // tables in global memory
             mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
@@ -1517,25 +1563,10 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // SIMD, 32 entries x 256 lanes x 4 B = 32 KB per workgroup only 5): as many entries as the deepest tree needs
             mq.sc.bvh_stack = t->bvh_stack;
             KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
-            if (first) {
-                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(0, hipLaunchKernelGGL((k_bounce<true, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            } else {
-                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 2, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(1, hipLaunchKernelGGL((k_bounce<false, 2>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            }
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
-            // the specialised kernel where its assumptions hold (see k_bounce)
-            // (depth of field only concerns the kernel that generates the camera rays)
-            const bool fast = fast_unsplit && !bp.emit_count && !(first && t->opt.depth_of_field);
-            if (first) {
-                if (fast) KT(0, hipLaunchKernelGGL((k_bounce<true, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(0, hipLaunchKernelGGL((k_bounce<true, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            } else {
-                if (fast) KT(1, hipLaunchKernelGGL((k_bounce<false, 0, true>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-                else KT(1, hipLaunchKernelGGL((k_bounce<false, 0>), dim3(gx, K), dim3(TILE), lds_bounce, stream, bp));
-            }
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
         }
 
         if (first && fill_cache) {
@@ -1913,6 +1944,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // (7680 x 4320: 6.2 -> 4.75 ms per iteration); needs the per-iteration radiance buffers
     t->lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
     t->no_fast = getenv("PTX_DEBUG_NO_FAST") != nullptr;
+    t->force_fast = getenv("PTX_DEBUG_FORCE_FAST") != nullptr;
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));

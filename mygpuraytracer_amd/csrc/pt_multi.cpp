@@ -5,11 +5,14 @@
 // Python or torch.distributed.  Device i of n traces the interleaved row blocks (y / tile_rows) % n == i of the frame as a
 // stream of its own (ptx_options.tile_*), with its own streams and buffers; nothing is exchanged while tracing.  One
 // exchange per read: the row blocks a device owns are copied into device[0]'s frame with one strided peer copy per device
-// (hipMemcpy2DAsync over xGMI: rows = blocks, pitch = n blocks) -- the gather SURVEY 8(e) names; foreign rows of every
+// (hipMemcpy2DAsync over xGMI: rows = blocks, pitch = n blocks; block-wise hipMemcpyPeerAsync for a device on which peer
+// access to device[0] could not be enabled) -- the gather SURVEY 8(e) names; foreign rows of every
 // device's own buffer stay zero, so an RCCL reduce(SUM) of the buffers would give the same frame bit for bit.
 // Parity: every tile equals the oracle run on that tile (stream indices are local to a tile).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -69,11 +72,19 @@ struct ptx_multi_worker {
 struct ptx_multi {
     std::vector<ptx_tracer *> tr;
     std::vector<int> dev;
+    std::vector<char> peer;                                      // peer[i]: device i can write device 0's memory directly (or is device 0)
     std::vector<std::unique_ptr<ptx_multi_worker>> workers;      // one per device when there are several
     int W = 0, H = 0, tile_rows = 0;
 };
 
 namespace {
+// The entry points below switch the calling thread's current device (hipSetDevice); a caller shaped like the reference's main.cpp
+// owns allocations and GL interop on ITS device and must find it current again after every call, error paths included.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) { saved = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
 int fail(int code, const std::string &msg) { ptx_internal_set_error(msg.c_str()); return code; }
 #define MHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 }  // namespace
@@ -85,6 +96,7 @@ int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *
     *out = nullptr;
     if (!s || !devices || ndevices < 1 || ndevices > 64) return fail(PTX_ERR_INVALID, "ptx_multi_create: need a scene and 1..64 device ordinals");
     if (tile_rows < 1) tile_rows = 8;
+    DeviceGuard guard;
     const int have = ptx_device_count();
     if (have < 1) return fail(PTX_ERR_NODEVICE, "no HIP device available; this library has no CPU path");
     for (int i = 0; i < ndevices; i++)
@@ -106,16 +118,23 @@ int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *
         }
         m->tr.push_back(t); m->dev.push_back(devices[i]);
     }
-    // peer access device[0] <-> the others, so that the gather is a direct xGMI copy (already-enabled is fine; where it
-    // cannot be enabled the copies still work, staged by the runtime)
+    // Peer access device[i] -> device[0], so that the gather is one strided copy written straight over xGMI.  Whether it really
+    // is enabled is RECORDED per device: a rectangular device-to-device copy into memory the copying device has no mapping of
+    // is not staged by the runtime the way a linear peer copy is -- ptx_multi_assemble takes the linear peer copies (one per
+    // row block, hipMemcpyPeerAsync, which the runtime may stage) for such a device instead.
+    m->peer.assign((size_t)ndevices, 1);
+    if (getenv("PTX_DEBUG_NO_PEER"))          // tests: take the block-wise path on every device but the first, whatever the hardware offers
+        for (int i = 1; i < ndevices; i++) m->peer[(size_t)i] = 0;
     for (int i = 1; i < ndevices; i++)
-        if (devices[i] != devices[0]) {
+        if (devices[i] != devices[0] && m->peer[(size_t)i]) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
-                hipSetDevice(devices[i]);
-                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                if (e != hipSuccess) (void)hipGetLastError();
+            bool ok = false;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can && hipSetDevice(devices[i]) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
             }
+            (void)hipGetLastError();
+            m->peer[(size_t)i] = ok ? 1 : 0;
         }
     if (ndevices > 1)
         for (int i = 0; i < ndevices; i++) {
@@ -130,6 +149,7 @@ int ptx_multi_create(const ptx_scene *s, const ptx_options *options, const int *
 
 void ptx_multi_destroy(ptx_multi *m) {
     if (!m) return;
+    DeviceGuard guard;
     for (auto &w : m->workers) w->stop();
     for (ptx_tracer *t : m->tr) ptx_destroy(t);
     delete m;
@@ -138,12 +158,13 @@ void ptx_multi_destroy(ptx_multi *m) {
 int ptx_multi_device_count(const ptx_multi *m) { return m ? (int)m->tr.size() : 0; }
 ptx_tracer *ptx_multi_tracer(ptx_multi *m, int i) { return (m && i >= 0 && i < (int)m->tr.size()) ? m->tr[i] : nullptr; }
 
-#define FOR_ALL(call) do { if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi"); for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } while (0)
+#define FOR_ALL(call) do { if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi"); DeviceGuard guard_; for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } while (0)
 int ptx_multi_set_camera(ptx_multi *m, const ptx_camera *camera, int trace_depth) { FOR_ALL(ptx_set_camera(t, camera, trace_depth)); }
 int ptx_multi_reset_image(ptx_multi *m) { FOR_ALL(ptx_reset_image(t)); }
 // the same call on every device at once, each from that device's own host thread; the first failure (in device order) is reported
 #define PAR_ALL(call) do {                                                                                              \
         if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi");                                                        \
+        DeviceGuard guard_;                                                                                            \
         if (m->workers.empty()) { for (ptx_tracer *t : m->tr) { int rc_ = (call); if (rc_ != PTX_OK) return rc_; } return PTX_OK; } \
         for (size_t i_ = 0; i_ < m->tr.size(); i_++) { ptx_tracer *t = m->tr[i_]; m->workers[i_]->submit([=]() -> int { return (call); }); } \
         int first_rc = PTX_OK; std::string first_err;                                                                  \
@@ -163,6 +184,7 @@ int ptx_multi_synchronize(ptx_multi *m) { FOR_ALL(ptx_synchronize(t)); }
 int ptx_multi_assemble(ptx_multi *m) {
     if (!m) return fail(PTX_ERR_INVALID, "null ptx_multi");
     const int n = (int)m->tr.size();
+    DeviceGuard guard;
     if (n == 1) return ptx_synchronize(m->tr[0]);
     const size_t row_bytes = (size_t)m->W * 3 * sizeof(float), blk_bytes = row_bytes * m->tile_rows;
     const int nblocks = (m->H + m->tile_rows - 1) / m->tile_rows;
@@ -175,6 +197,14 @@ int ptx_multi_assemble(ptx_multi *m) {
         // tile_rows) on its own
         int mine = 0, whole = 0;
         for (int b = i; b < nblocks; b += n) { mine++; if ((b + 1) * m->tile_rows <= m->H) whole++; }
+        if (!m->peer[(size_t)i]) {                 // no mapping of device 0's memory on this device: linear peer copies, block by block
+            for (int b = i; b < nblocks; b += n) {
+                const size_t off = (size_t)b * blk_bytes;
+                const size_t bytes = std::min(blk_bytes, (size_t)(m->H - b * m->tile_rows) * row_bytes);
+                MHIP(hipMemcpyPeerAsync(dst0 + off, m->dev[0], src + off, m->dev[i], bytes, st));
+            }
+            continue;
+        }
         if (whole > 0)
             MHIP(hipMemcpy2DAsync(dst0 + (size_t)i * blk_bytes, (size_t)n * blk_bytes, src + (size_t)i * blk_bytes, (size_t)n * blk_bytes,
                                   blk_bytes, (size_t)whole, hipMemcpyDeviceToDevice, st));
@@ -192,6 +222,7 @@ float *ptx_multi_device_image(ptx_multi *m) { return m ? ptx_device_image(m->tr[
 
 int ptx_multi_read_image(ptx_multi *m, float *host_rgb) {
     if (!m || !host_rgb) return fail(PTX_ERR_INVALID, "null argument");
+    DeviceGuard guard;
     int rc = ptx_multi_assemble(m);
     if (rc != PTX_OK) return rc;
     return ptx_read_image(m->tr[0], host_rgb);
@@ -201,6 +232,7 @@ int ptx_multi_read_image(ptx_multi *m, float *host_rgb) {
 int ptx_multi_read_albedo(ptx_multi *m, float *host_rgb) {
     if (!m || !host_rgb) return fail(PTX_ERR_INVALID, "null argument");
     const int n = (int)m->tr.size();
+    DeviceGuard guard;
     if (n == 1) return ptx_read_albedo(m->tr[0], host_rgb);
     std::vector<float> tmp((size_t)m->W * m->H * 3);
     const size_t row = (size_t)m->W * 3;
@@ -233,6 +265,7 @@ int ptx_unpin_host_buffer(void *p) {
 int ptx_multi_get_stats(ptx_multi *m, ptx_stats *out) {
     if (!m || !out) return fail(PTX_ERR_INVALID, "null argument");
     memset(out, 0, sizeof *out);
+    DeviceGuard guard;
     for (size_t i = 0; i < m->tr.size(); i++) {
         ptx_stats s;
         int rc = ptx_get_stats(m->tr[i], &s);

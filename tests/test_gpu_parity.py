@@ -1098,13 +1098,18 @@ def _oracle_tiles(O, s, world, tile_rows, iters, **opt):
     return total, rays
 
 
+@pytest.mark.parametrize("no_peer", [False, True])
 @pytest.mark.parametrize("res,devices,tile_rows", [((96, 64), [0, 0], 8), ((100, 60), [0, 0, 0], 8), ((64, 37), [0, 0, 0, 0], 4)])
-def test_several_devices_behind_the_c_abi(gpu_product, O, res, devices, tile_rows):
+def test_several_devices_behind_the_c_abi(gpu_product, O, monkeypatch, res, devices, tile_rows, no_peer):
     """ptx_multi_*: one process, one tracer per listed device (here the same GPU several times -- what a one-GPU box can
     check), each tracing its interleaved row blocks; ptx_multi_read_image copies the blocks into device[0]'s frame.  Equals
     the oracle's tiles assembled, bit for bit, including frames whose height is not a multiple of the block (cut-off last
-    block) and ranks that own one block less; rays summed over the devices."""
+    block) and ranks that own one block less; rays summed over the devices.  no_peer: the gather a device takes when peer access to
+    device[0] could not be enabled (block-wise linear peer copies instead of one strided copy; PTX_DEBUG_NO_PEER forces it here).
+    The calling thread's current device is what it was before every call."""
     pt = gpu_product
+    if no_peer:
+        monkeypatch.setenv("PTX_DEBUG_NO_PEER", "1")
     s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=res, depth=6)
     s.apply_runcuda_camera()
     want, rays = _oracle_tiles(O, s, len(devices), tile_rows, 3)
@@ -1166,6 +1171,48 @@ def test_specialised_and_general_bounce_kernels_agree(gpu_product, monkeypatch, 
     with gpu_product.Tracer(s, **opt) as B:
         B.render(1, 5)
         assert beq(B.read_image(), img) and B.stats()["rays_total"] == st["rays_total"]
+
+
+@pytest.mark.parametrize("scene,opt,why", [("cornellObj.txt", dict(sort_by_material=0), "sort_by_material"),
+                                             ("cornell.txt", dict(antialiasing=0), "cache-filling"),
+                                             ("cornellObj.txt", dict(depth_of_field=1), "depth of field"),
+                                             ("cornellObj.txt", dict(batch=1, lanes=1), "radiance buffers"),
+                                             ("cornellSpaceship.txt", dict(no_mesh_split=1), "split mesh|textured|BVH")])
+def test_specialised_kernel_is_refused_outside_its_preconditions(gpu_product, monkeypatch, scene, opt, why):
+    """Round 2's GPU fault came from a build that launched k_bounce<.., FAST> where the values it hard-wires did not
+    hold (sort_by_material = 0: one bin on the host, nmats bins in the kernel).  The preconditions now live in ONE host predicate
+    (fast_violation) that every launch goes through; asked for the variant regardless (PTX_DEBUG_FORCE_FAST), ptx_render answers
+    PTX_ERR_INVALID and names the assumption -- nothing is launched -- and without the request the same tracer renders what the
+    general kernel renders."""
+    import re
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", scene), res=(96, 64), depth=4)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s, **opt) as A:
+        A.render(1, 3)
+        img = A.read_image()
+    monkeypatch.setenv("PTX_DEBUG_FORCE_FAST", "1")
+    with gpu_product.Tracer(s, **opt) as B:
+        with pytest.raises(gpu_product.PathTracerError) as e:
+            B.render(1, 3)
+        assert re.search("outside its preconditions.*(%s)" % why, str(e.value)), str(e.value)
+    monkeypatch.delenv("PTX_DEBUG_FORCE_FAST")
+    monkeypatch.setenv("PTX_DEBUG_NO_FAST", "1")
+    with gpu_product.Tracer(s, **opt) as C:
+        C.render(1, 3)
+        assert beq(C.read_image(), img)
+
+
+def test_forced_specialised_kernel_where_it_applies(gpu_product, monkeypatch):
+    """... and where every precondition holds the request changes nothing (C4's option set, any frame size)."""
+    s = gpu_product.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(96, 64), depth=4)
+    s.apply_runcuda_camera()
+    with gpu_product.Tracer(s) as A:
+        A.render(1, 6)
+        img = A.read_image()
+    monkeypatch.setenv("PTX_DEBUG_FORCE_FAST", "1")
+    with gpu_product.Tracer(s) as B:
+        B.render(1, 6)
+        assert beq(B.read_image(), img)
 
 
 def test_several_devices_apps_variant(gpu_product, O):

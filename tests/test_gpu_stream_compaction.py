@@ -86,6 +86,37 @@ def test_device_pointer_forms(gpu_product, n):
         assert np.array_equal(d_in.cpu().numpy(), want_scan)
 
 
+@pytest.mark.parametrize("n", [1, 5, 4096, 16385, 1920 * 1080 + 3])
+def test_common_kernels_build_the_reference_pipeline(gpu_product, n):
+    """StreamCompaction::Common::kernMapToBoolean / kernScatter (stream_compaction/common.cu:25-49) as sc_map_to_boolean_device /
+    sc_scatter_device: the reference's own compaction, map -> exclusive scan -> scatter (efficient.cu:100-125), put together from the
+    three device entry points equals sc_compact_device and numpy, integer for integer -- aligned and 4-byte-aligned-only views."""
+    import torch
+    sc = gpu_product.StreamCompaction()
+    rng = np.random.default_rng(n)
+    a = (rng.integers(-4, 9, n) * (rng.random(n) < 0.4)).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    ws = torch.zeros((sc.workspace_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
+    for shift in (0, 1):
+        store = [torch.zeros(n + 1, dtype=torch.int32, device=dev) for _ in range(4)]
+        d_in, d_bools, d_idx, d_out = [b[shift:shift + n] for b in store]
+        d_in.copy_(torch.from_numpy(a))
+        d_bools.fill_(-5); d_out.fill_(-77)
+        torch.cuda.synchronize()
+        sc.map_to_boolean_device(n, d_bools.data_ptr(), d_in.data_ptr())
+        sc.scan_device(n, d_idx.data_ptr(), d_bools.data_ptr(), ws.data_ptr())
+        sc.scatter_device(n, d_out.data_ptr(), d_in.data_ptr(), d_bools.data_ptr(), d_idx.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_bools.cpu().numpy(), (a != 0).astype(np.int32))
+        keep = a[a != 0]
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:len(keep)], keep) and np.all(got[len(keep):] == -77)
+        assert store[1][n if shift == 0 else 0].item() == 0                    # nothing written outside the n elements
+    sc.map_to_boolean_device(0, 0, 0)                                          # n = 0: nothing happens
+    with pytest.raises(gpu_product.PathTracerError):
+        sc.scatter_device(4, 0, 0, 0, 0)
+
+
 def test_device_forms_degenerate(gpu_product):
     import torch
     sc = gpu_product.StreamCompaction()

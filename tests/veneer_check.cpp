@@ -45,9 +45,13 @@ int main(int argc, char **argv) {
     const size_t n = (size_t)w * h;
     uchar4 *pbo = nullptr;                             // HIP's own uchar4, as in a maintainer's main.cpp
     if (hipMalloc((void **)&pbo, n * 4) != hipSuccess || hipMemset(pbo, 0x5a, n * 4) != hipSuccess) { fprintf(stderr, "no device pbo\n"); return 1; }
+    // the reference's exact signatures exist where uchar4 is known (src/pathtrace.h:9, apps/src/pathtrace.h:10)
+    void (*ref_pathtrace)(uchar4 *, int, int) = &pathtrace;
+    void (*ref_send)(uchar4 *, int) = &sendToGPU;
     float sum = 0.f;
     for (int it = 1; it <= iters; it++) {
-        pathtrace(pbo, 0, it);
+        if (it & 1) ref_pathtrace(pbo, 0, it);
+        else pathtrace(pbo, 0, it);
         sum += timer().getGpuElapsedTimeForPreviousOperation();
     }
     std::vector<unsigned char> host(n * 4);
@@ -61,11 +65,12 @@ int main(int argc, char **argv) {
             scene->state.output[i].y = scene->state.image[i].y / iters;
             scene->state.output[i].z = scene->state.image[i].z / iters * 3.0f;
         }
-        sendToGPU(pbo, iters);
+        ref_send(pbo, iters);
         if (hipMemcpy(host.data(), pbo, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
         dump(out + ".pbo2", host.data(), n * 4);
     }
     printf("time: %g\n", sum);
+    (void)ref_send;
     (void)hipFree(pbo);
     pathtraceFree();
     pathtraceFree();                                   // idempotent
