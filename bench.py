@@ -25,10 +25,28 @@ sys.path.insert(0, ROOT)
 WORKLOAD = "cornellObj.txt 1920x1080 depth 8, AA on, material sort on, 1 spp/step (BASELINE configs[3] / C4)"
 SCENE, RES, DEPTH = "cornellObj.txt", (1920, 1080), 8
 HBM_PEAK = 8.0e12                 # MI355X HBM3E spec peak, B/s (MI355X_MICROARCH.md)
-# algorithmic bytes per ray-bounce from the reference's record sizes: intersect 76 + shade 120 are what
-# k_bounce does, material sort 152 + compaction 88 what k_move does; 436 in total for the loop
-BYTES_BOUNCE_KERNEL = 76 + 120
-BYTES_LOOP = 436
+VALU_PEAK = 256 * 4 * 16 * 2.4e9  # lane-slots/s of non-packed, non-FMA vector issue: CUs x SIMDs x 16 lanes x 2.4 GHz (same guide)
+# The CONTRACT's algorithmic bytes per ray-bounce, from the reference's 44-B PathSegment / 32-B ShadeableIntersection records
+# (SURVEY 8(d)): intersect 76 + shade 120 for what k_bounce does, + material sort 152 + compaction 88 = 436 for the loop.  This design
+# moves 60-B SoA records once per bounce and no dead paths, so those figures are reported under explicit `contract_*` names only.
+CONTRACT_BYTES_BOUNCE_KERNEL = 76 + 120
+CONTRACT_BYTES_LOOP = 436
+
+
+def own_layout_bytes(rpb):
+    """Algorithmic bytes per ray of k_bounce (bounces >= 1) by THIS design's data layout, from the rays per bounce:
+    a ray entering bounce b reads its local-index entry (8 B) and its record (12 floats + slot + material|geom = 56 B); if it is
+    stored for bounce b + 1 it writes the 56-B record, its 4-B key and, in the kernel's tail, its 8-B local-index entry (re-reading the
+    key: 4 B); otherwise it writes 12 B of radiance and the 4-B empty key."""
+    n = [float(x) for x in rpb] + [0.0]
+    tot = sum(n[1:-1])
+    if tot <= 0:
+        return 0.0
+    b = 0.0
+    for k in range(1, len(n) - 1):
+        stored = n[k + 1]
+        b += n[k] * (8 + 56) + stored * (56 + 4 + 8 + 4) + (n[k] - stored) * (12 + 4)
+    return b / tot
 
 
 def usable_cores():
@@ -152,6 +170,63 @@ def cpu_baseline(scene, iters):
                 stage_seconds=dict(intersect=sec[0], sort=sec[1], shade=sec[2], compact=sec[3], generate=sec[4], gather=sec[5]))
 
 
+def dropin_per_call(torch, pt, scene, dev_index, calls=96):
+    """The reference's own call shape, driver-visible: per call what the C++ veneer's pathtrace(pbo, frame, iter) does
+    (csrc/pathtrace_api.cpp; src/pathtrace.cu:434-436, :552-556) -- camera refresh, ONE iteration, the 8-bit preview into a device
+    pbo, the fp32 frame copied back into a page-locked host buffer -- so that scene->state.image is valid after every call.
+    Render-ahead on, as in the veneer.  ms per call over `calls` calls; the PCIe copy alone is the floor."""
+    import ctypes as C
+    import numpy as np
+    W, H = RES
+    vp = C.c_void_p
+    with pt.Tracer(scene, device=dev_index) as T:
+        lib, h = T.lib, T.h
+        T.set_render_ahead(True)
+        img = np.zeros((W * H, 3), np.float32)
+        pinned = lib.ptx_pin_host_buffer(img.ctypes.data_as(vp), img.nbytes) == 0
+        pbo = torch.zeros(W * H * 4, dtype=torch.uint8, device=torch.device("cuda", dev_index))
+        torch.cuda.synchronize()
+
+        def call(it):
+            T.set_camera(scene)
+            T.pathtrace(it)
+            lib.ptx_write_pbo_device(h, it, vp(pbo.data_ptr()))
+            lib.ptx_read_image(h, img.ctypes.data_as(vp))
+        for it in range(1, 37):
+            call(it)
+        t0 = time.perf_counter()
+        for it in range(37, 37 + calls):
+            call(it)
+        per_call = (time.perf_counter() - t0) / calls * 1e3
+        t0 = time.perf_counter()
+        for _ in range(16):
+            lib.ptx_read_image(h, img.ctypes.data_as(vp))
+        copy_ms = (time.perf_counter() - t0) / 16 * 1e3
+        if pinned:
+            lib.ptx_unpin_host_buffer(img.ctypes.data_as(vp))
+    return per_call, copy_ms
+
+
+def c5_per_iteration(pt, dev_index, iters=24):
+    """BASELINE configs[4] on ONE GPU: the cornellSpaceship layout at 3840x2160, depth 8, antialiasing + depth of field, textured
+    BVH mesh (the 20448-triangle procedural stand-in: the reference's .obj is missing), split mesh search.  ms per iteration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import ensure_standin_assets
+    ensure_standin_assets()
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=(3840, 2160), depth=8)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, depth_of_field=1, device=dev_index) as T:
+        T.render(1, 12)
+        T.synchronize()
+        r0 = T.stats()["rays_total"]
+        t0 = time.perf_counter()
+        T.render(100, iters)
+        T.synchronize()
+        dt = time.perf_counter() - t0
+        rays = T.stats()["rays_total"] - r0
+    return dt / iters * 1e3, rays / iters
+
+
 def stream_compaction_device(torch, pt, device):
     """the scan / compaction library on arrays already in HBM (sc_scan_device, sc_compact_device): achieved
     rate on algorithmic bytes (scan 4 B read + 4 B written per element; compaction 4 B read + 4 B per survivor) next to a
@@ -196,6 +271,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip dropin_per_call_ms and c5_ms_per_iteration (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks: the frame is then reduced through host memory)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
@@ -344,11 +420,13 @@ def main():
     else:
         units = rays_leg * (rpb[0] / max(sum(rpb), 1)) / max(dom_n, 1)
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
-    achieved = BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
-    # HBM bytes per launch from the PMC counters need rocprofv3, so they are NOT measured in this run: they come from the
-    # committed profile of the same command (tools/profile_round.sh -> profiles/traffic_latest.json), scaled from that
-    # profile's rays per launch to this run's, and are labelled as such.
-    traffic = traffic_source = physical = None
+    own_bytes = own_layout_bytes(rpb) if dominant == "k_bounce" else 8.0 + 56 + 4 + 8 + 4      # (first bounce: nothing read, mostly stored)
+    achieved = own_bytes * units / avg_s if avg_s > 0 else 0.0
+    contract = CONTRACT_BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
+    # HBM bytes and instruction counts per launch come from PMC counters, which need rocprofv3: they are NOT measured in this run but
+    # taken from the committed profile of the same kernels (tools/profile_round.sh, tools/pmc_sq.sh -> profiles/), scaled from that
+    # profile's rays per launch to this run's, and labelled as such.
+    traffic = traffic_source = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
@@ -357,33 +435,51 @@ def main():
             ref_units = (tjd.get("_units_per_launch") or {}).get(dominant)
             if per_launch is not None:
                 traffic = per_launch * (units / ref_units) if ref_units else per_launch
-                traffic_source = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --lanes 1`, "
-                                  "not this run; %s)" % ("scaled by rays per launch %.3g / %.3g" % (units, ref_units) if ref_units
-                                                         else "per launch of that profile, unscaled"))
-                if avg_s > 0:
-                    physical = dict(GBps=traffic / avg_s / 1e9, frac=traffic / avg_s / HBM_PEAK,
-                                    bytes_per_unit=traffic / max(units, 1))
+                traffic_source = ("profiles/traffic_latest.json = %s, not this run; %s" % (
+                    tjd.get("_how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline`"),
+                    "scaled by rays per launch %.3g / %.3g" % (units, ref_units) if ref_units else "per launch of that profile, unscaled"))
         except Exception:
             traffic = None
-    loop_achieved = BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel=dominant, achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=achieved / HBM_PEAK, traffic=traffic, traffic_source=traffic_source,
-                    # what the kernel physically moves (PMC bytes / measured launch time): it is not HBM-bound in practice --
-                    # `achieved`/`frac` are the contract's algorithmic bytes (reference record sizes)
-                    physical=physical, bound_in_practice="VALU issue + latency (bit-exact IEEE arithmetic), see DESIGN.md 5",
-                    effective_vs_reference_layout=dict(bytes_per_unit=BYTES_BOUNCE_KERNEL, GBps=achieved / 1e9, frac=achieved / HBM_PEAK),
-                    avg_launch_us=avg_s * 1e6, launches=dom_n, units_per_launch=units,
-                    algorithmic_bytes_per_unit=BYTES_BOUNCE_KERNEL,
-                    loop=dict(achieved=loop_achieved / 1e9, frac=loop_achieved / (HBM_PEAK * world), bytes_per_ray=BYTES_LOOP,
-                              loop_ms_per_step=loop_ms / args.steps),
+    valu_issue = None
+    sj = os.path.join(ROOT, "profiles", "sq_latest.json")
+    if os.path.exists(sj):
+        try:
+            sq = json.load(open(sj))
+            k = sq.get(dominant) or {}
+            ref_units = (sq.get("_units_per_launch") or {}).get(dominant)
+            if k.get("SQ_INSTS_VALU") and avg_s > 0:
+                insts = k["SQ_INSTS_VALU"] * (units / ref_units if ref_units else 1.0)
+                lane_slots = insts * 64 / avg_s
+                valu_issue = dict(achieved=lane_slots / 1e12, peak=VALU_PEAK / 1e12, unit="T lane-slots/s", frac=lane_slots / VALU_PEAK,
+                                  wave_instructions_per_launch=insts, lanes_active=(k.get("_derived") or {}).get("valu_lane_utilisation"),
+                                  source="profiles/sq_latest.json (SQ_INSTS_VALU per launch from %s, not this run%s) x 64 lanes / this run's "
+                                         "launch time / (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)" % (
+                                             sq.get("_how", "tools/pmc_sq.sh"), "; scaled by rays per launch" if ref_units else ""))
+        except Exception:
+            valu_issue = None
+    loop_contract = CONTRACT_BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
+    # One read tells what bounds the kernel: `bound` names it (vector-instruction issue -- valu_issue.frac of the issue peak), achieved /
+    # frac / traffic are the HBM side of the same launches by this design's own bytes; the contract's record sizes are under contract_*.
+    roofline = dict(bound="valu" if valu_issue and valu_issue["frac"] > achieved / HBM_PEAK else "hbm", kernel=dominant,
+                    achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
+                    algorithmic_bytes_per_unit=own_bytes, traffic=traffic, traffic_source=traffic_source,
+                    traffic_over_algorithmic=(traffic / (own_bytes * units)) if traffic and own_bytes else None,
+                    physical_frac=(traffic / avg_s / HBM_PEAK) if traffic and avg_s > 0 else None,
+                    valu_issue=valu_issue,
+                    contract_196B_frac=contract / HBM_PEAK,            # 196 B/ray of the reference's AoS records / launch time / 8 TB/s
+                    contract_436B_loop_ratio=loop_contract / (HBM_PEAK * world),     # a RATIO (may exceed 1): the reference layout's loop bytes
+                                                                                     # per ray / wall time of the bounce loop / 8 TB/s
+                    avg_launch_us=avg_s * 1e6, launches=dom_n, units_per_launch=units, loop_ms_per_step=loop_ms / args.steps,
                     kernels_ms_per_step={k: v[0] / args.steps for k, v in kt.items()},
-                    timing="kernel durations: hipEvents around every launch, one launch set at a time (lanes 1); value, ms_per_step "
-                           "and loop: wall time with %d launch set(s) in flight" % (args.lanes if args.lanes >= 1 else 3))
+                    timing="kernel durations: hipEvents around every launch, one launch set at a time (lanes 1), NOT additive to ms_per_step: "
+                           "value, ms_per_step and loop_ms_per_step are wall time with %d launch set(s) in flight" % (args.lanes if args.lanes >= 1 else 3))
 
     out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
                config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
+                           rccl_ranks=(dist.get_world_size() if dist_on else 1), backend=(args.backend if dist_on else None),
+                           exchange=(None if not dist_on else "reduce" if by_iter else args.exchange),
                            timed_region_ms=dt * 1e3, slowest_rank_render_ms=t_render_max * 1e3,
                            exchange_and_barrier_ms=(dt - t_render_max) * 1e3 if dist_on else 0.0,
                            parallelism=("1 GPU" if world == 1 else
@@ -393,6 +489,26 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)
     T.close()
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # two more driver-visible figures, outside the timed region: the reference's one-iteration-per-call shape with the frame
+        # read back every call (PCIe-inclusive: never `value`), and BASELINE configs[4] (4K, textured BVH mesh, DoF) on one GPU
+        try:
+            per_call, copy_ms = dropin_per_call(torch, pt, scene, dev_index)
+            out["dropin_per_call_ms"] = per_call
+            out["dropin_per_call"] = dict(ms=per_call, frame_copy_alone_ms=copy_ms, Mrays_per_s=rays / args.steps / per_call / 1e3,
+                                          what="C ABI sequence of the veneer's pathtrace(pbo, frame, iter): set_camera + 1 iteration + preview "
+                                               "into a device pbo + fp32 frame into pinned host memory, per call, render-ahead on")
+        except Exception as e:
+            out["dropin_per_call_ms"] = None
+            out["dropin_per_call"] = dict(error=str(e)[:200])
+        try:
+            c5_ms, c5_rays = c5_per_iteration(pt, dev_index)
+            out["c5_ms_per_iteration"] = c5_ms
+            out["c5"] = dict(ms_per_iteration=c5_ms, rays_per_iteration=c5_rays, Mrays_per_s=c5_rays / c5_ms / 1e3,
+                             workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, 1 GPU (BASELINE configs[4] / C5)")
+        except Exception as e:
+            out["c5_ms_per_iteration"] = None
+            out["c5"] = dict(error=str(e)[:200])
     if rank == 0 and world == 1:
         out["stream_compaction"] = stream_compaction_device(torch, pt, device)
     if rank == 0:

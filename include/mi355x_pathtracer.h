@@ -247,7 +247,7 @@ int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */
 int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, int nrays, int32_t *face_loop, float *t_loop,
                         int32_t *face_bvh, float *t_bvh, int64_t *stats4);
 /* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
-int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]);
+int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out48[48]);
 /* fields14 (optional): 14 rows of min(n, cap) floats: px py pz (= origin + t*direction, the point that will be
  * shaded) dx dy dz cr cg cb nx ny nz u v (u, v only meaningful when the scene has textures) */
 int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32_t *stream_idx,

@@ -247,6 +247,10 @@ struct DScene {
     int32_t mesh_chunks;                // > 1: no mesh has a BVH and the longest has this many groups of MESH_CHUNK faces:
                                         // tileIntersect spreads every (ray, mesh) pair over that many lanes
     int32_t cull;                       // != 0: per-lane candidate lists from the world boxes (needs tri_lds, <= 32 geoms)
+    const float *__restrict__ ldsblob;  // the tables below in ONE array, in the order and with the ntri_lds the launch stages them
+                                        // (tri9, faces, materials, gtab, fnorm, cnorm): a workgroup copies it to LDS with all its loads in
+                                        // flight at once -- one memory round trip, where table after table was six (it matters for the
+                                        // short kernels of a small tile, which are chains of such round trips); NULL: table by table
 };
 
 // Words of dynamic LDS the staged scene tables take (tri9 + faces + fnorm = 27 per staged triangle, 11 per material, gtab 40 +
@@ -259,9 +263,21 @@ constexpr int GTAB_WORDS = 40;
 // dynamic LDS of the kernels that use this header: [scene tables when sc.tri_lds][kernel-specific scratch]
 extern __shared__ __attribute__((aligned(16))) int32_t pt_lds[];
 
-// Copies the scene tables into LDS (call from every thread of the workgroup, then __syncthreads()).
+// Copies the scene tables into LDS (call from `nthreads` threads of the workgroup with tid 0 .. nthreads - 1, then __syncthreads()).
 __device__ __forceinline__ void stageSceneToLds(const DScene &sc, int tid, int nthreads) {
     float *l = reinterpret_cast<float *>(pt_lds);
+    if (sc.ldsblob) {
+        const int n = sc.ntri_lds * 27 + sc.nmats * 11 + sc.ngeoms * 58;
+        for (int k = tid; k < n; k += 4 * nthreads) {           // four loads requested before the first is stored
+            const int k1 = k + nthreads, k2 = k1 + nthreads, k3 = k2 + nthreads;
+            const float a0 = sc.ldsblob[k], a1 = k1 < n ? sc.ldsblob[k1] : 0.f, a2 = k2 < n ? sc.ldsblob[k2] : 0.f, a3 = k3 < n ? sc.ldsblob[k3] : 0.f;
+            l[k] = a0;
+            if (k1 < n) l[k1] = a1;
+            if (k2 < n) l[k2] = a2;
+            if (k3 < n) l[k3] = a3;
+        }
+        return;
+    }
     const int n9 = sc.ntri_lds * 9, n15 = sc.ntri_lds * 15, nm = sc.nmats * 11;
     for (int k = tid; k < n9; k += nthreads) l[k] = sc.tri9[k];
     for (int k = tid; k < n15; k += nthreads) l[n9 + k] = sc.faces[k];

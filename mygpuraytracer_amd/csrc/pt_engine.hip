@@ -478,6 +478,40 @@ __device__ __forceinline__ int scanFind(const int32_t *cs, const int32_t *ca, in
     }
     return -1;
 }
+// The same search with EIGHT consecutive entries per lane: 512 entries per memory round trip instead of 64 (the loads of a trip are
+// all requested before the first is used).  The tables searched this way are short (bins x groups of 64 workgroups).
+__device__ __forceinline__ int scanFind8(const int32_t *cs, const int32_t *ca, int n, int A, int &pre_s, int &pre_a, int lane) {
+    for (int base = 0; base < n; base += 512) {
+        int vs[8], va[8];
+        const int k0 = base + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { vs[j] = k0 + j < n ? cs[k0 + j] : 0; va[j] = k0 + j < n ? ca[k0 + j] : 0; }
+        int ss = 0, sa = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { ss += vs[j]; sa += va[j]; }
+        const int is = waveInclusiveScan(ss, lane), ia = waveInclusiveScan(sa, lane);
+        const unsigned long long m = __ballot(pre_s + is > A);
+        if (m) {
+            const int l = __ffsll((long long)m) - 1;                 // the lane whose eight entries hold the answer
+            pre_s += __builtin_amdgcn_readlane(is - ss, l);
+            pre_a += __builtin_amdgcn_readlane(ia - sa, l);
+            int found = -1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                            // (uniform: every lane walks lane l's entries)
+                const int es = __builtin_amdgcn_readlane(vs[j], l), ea = __builtin_amdgcn_readlane(va[j], l);
+                if (found < 0) {
+                    if (pre_s + es > A) found = base + l * 8 + j;
+                    else { pre_s += es; pre_a += ea; }
+                }
+            }
+            return found;
+        }
+        pre_s += __builtin_amdgcn_readlane(is, 63);
+        pre_a += __builtin_amdgcn_readlane(ia, 63);
+    }
+    return -1;
+}
+
 // The window: runs [r0, r0 + WIN) of the table with their exclusive prefixes, in LDS (one wave; the caller brackets it with
 // barriers).  win[0 .. WIN] = first sorted position of each run and of what follows the window, win[WIN+1 .. 2*WIN+1] = the same
 // for the survivor counts (= the RNG stream index of a run's first survivor), then the runs' starts in the local index, then r0 + WIN.
@@ -522,6 +556,9 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
 __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
+#ifdef PT_WGCLOCK
+    const unsigned long long wg_t0 = wall_clock64();       // 100 MHz: latency of the workgroup's phases (prologue, tile loop, tail)
+#endif
     BounceParams p = p_in;
     if (FAST && MODE != 0) {             // the two halves of the split bounce: the subset that holds for textured BVH scenes too
         p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
@@ -547,7 +584,6 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + REC_WORDS);   // MODE 1: LDS stage of the (ray, mesh) queue, [QCAP], kept
     int32_t *qcnt = rec + REC_WORDS + QCAP, *qbase = qcnt + 1;        // across tiles (so not inside the record buffer)
     if (MODE == 1 && tid == 0) *qcnt = 0;
-    if (p.sc.tri_lds) stageSceneToLds(p.sc, tid, TILE);
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
     if (tid < 8) tcnt[tid] = 0;
     __syncthreads();
@@ -575,23 +611,52 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #else
 #define STAMP(k) do { } while (0)
 #endif
-    // Head of the sort: the run that holds this workgroup's first sorted position, found by wave 0 with three scans over at most
-    // 64 entries each (bins, groups of 64 workgroups of that bin, workgroups of that group), and the window of runs from there on.
+    // Head of the sort: the run that holds this workgroup's first sorted position, found by wave 0 in TWO memory round trips while
+    // the other waves stage the scene tables (the short kernels of a small tile are chains of such round trips: the prologue was
+    // a third of a workgroup's life there).  Trip 1: the flat [bin][group of 64 workgroups] table, eight entries per lane -> the
+    // group.  Trip 2: that group's 64 runs and the 64 after them, three tables -> the run, and from the same registers the window
+    // of the 64 runs from it on (what windowLoad would fetch in a third trip).
     if (!FIRST && MODE != 2 && tile0 < tile1) {
         if (wave == 0) {
             const int32_t *in_super = p.in_super + p.seg_in_totals * seg;
             const int A = tile0 * TILE;
             int pre_s = 0, pre_a = 0;
-            const int b = scanFind(in_totals + nb, in_totals, nb, A, pre_s, pre_a, lane);               // A < n_in: there is one
-            const int nsup = (p.in_gx + 63) >> 6;
-            const int sg = scanFind(in_super + (size_t)nb * p.nsuper + (size_t)b * p.nsuper, in_super + (size_t)b * p.nsuper, nsup, A, pre_s, pre_a, lane);
-            const int w0 = sg * 64, nw = min(64, p.in_gx - w0);
-            const int r0 = b * p.in_gx + w0;
-            const int w = scanFind(in_chunk + p.chunk_cap + r0, in_chunk + r0, nw, A, pre_s, pre_a, lane);
-            windowLoad(win, in_chunk, p.chunk_cap, in_nruns, r0 + w, pre_s, pre_a, lane);
-        }
+            // (rows of the group table are nsuper wide, entries past a bin's last group are zero: scanned as one flat array)
+            const int bs = scanFind8(in_super + (size_t)nb * p.nsuper, in_super, nb * p.nsuper, A, pre_s, pre_a, lane);      // A < n_in: there is one
+            const int b = bs / p.nsuper, sg = bs - b * p.nsuper;
+            const int rs = b * p.in_gx + sg * 64;                     // first run of the group; its 64 runs hold position A
+            int cs[2], ca[2], cb[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int r = rs + h * 64 + lane;
+                // (a bin's last group may hold fewer than 64 runs: what follows in the flat table is the next bin's first runs, which
+                // are also what follows in sorted order; position A itself lies in the group, i.e. in the first 64)
+                const bool in = r < in_nruns;
+                ca[h] = in ? in_chunk[r] : 0; cs[h] = in ? in_chunk[p.chunk_cap + r] : 0; cb[h] = in ? in_chunk[2 * p.chunk_cap + r] : 0;
+            }
+            int xs[2], xa[2];                                         // exclusive prefixes of the 128 entries
+            const int is0 = waveInclusiveScan(cs[0], lane), ia0 = waveInclusiveScan(ca[0], lane);
+            const int is1 = waveInclusiveScan(cs[1], lane), ia1 = waveInclusiveScan(ca[1], lane);
+            const int t0s = __builtin_amdgcn_readlane(is0, 63), t0a = __builtin_amdgcn_readlane(ia0, 63);
+            xs[0] = pre_s + is0 - cs[0]; xa[0] = pre_a + ia0 - ca[0];
+            xs[1] = pre_s + t0s + is1 - cs[1]; xa[1] = pre_a + t0a + ia1 - ca[1];
+            const unsigned long long m = __ballot(pre_s + is0 > A);
+            const int w = m ? __ffsll((long long)m) - 1 : 0;          // the run, as an offset into the group
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = h * 64 + lane - w;                      // this entry's place in the window that starts at run rs + w
+                if (e >= 0 && e < WIN) { win[e] = xs[h]; win[WIN + 1 + e] = xa[h]; win[2 * (WIN + 1) + e] = cb[h]; }
+                if (e == WIN) { win[WIN] = xs[h]; win[2 * WIN + 1] = xa[h]; win[2 * (WIN + 1) + WIN] = rs + w + WIN; }
+            }
+        } else if (p.sc.tri_lds) stageSceneToLds(p.sc, tid - 64, TILE - 64);
+        __syncthreads();
+    } else if (tile0 < tile1 && p.sc.tri_lds) {      // (a workgroup without tiles shades nothing and needs no tables)
+        stageSceneToLds(p.sc, tid, TILE);
         __syncthreads();
     }
+#ifdef PT_WGCLOCK
+    const unsigned long long wg_t1 = wall_clock64();
+#endif
     struct InRec { float f[14]; int32_t pix, mg, idx; };
     // sorted position -> (entry of the local index, RNG stream index of its run's first survivor).  Uniform call: the window
     // moves on (barriers) when the tile's last position lies beyond it -- a few times per workgroup at most.
@@ -928,6 +993,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     if (lane == 0 && p.stamps)
         for (int k = 0; k < 16; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
 #endif
+#ifdef PT_WGCLOCK
+    const unsigned long long wg_t2 = wall_clock64();
+#endif
     if (MODE == 1) {                     // counts belong to MODE 2; what is left in the LDS queue goes out now
         if (*qcnt > 0) flushQueue(p, seg, qbuf, qcnt, qbase, tid);
         return;
@@ -979,6 +1047,15 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             }
         }
     }
+#ifdef PT_WGCLOCK
+    // (diagnostic build -DPT_WGCLOCK: a slot of its own per (kind, segment of the first 64, workgroup) -- plain adds, no shared address)
+    if (tid == 0 && p.stamps && tile1 > tile0 && seg < 64 && blockIdx.x < 4096) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long wg_t3 = wall_clock64();
+        unsigned long long *w = p.stamps + 48 + ((size_t)((FIRST ? 0 : 1) * 64 + seg) * 4096 + blockIdx.x) * 5;
+        w[0] += wg_t1 - wg_t0; w[1] += wg_t2 - wg_t1; w[2] += wg_t3 - wg_t2; w[3] += 1ull; w[4] += (unsigned long long)(tile1 - tile0);
+    }
+#endif
 }
 
 // Split mesh search, middle part: one lane per queued (ray, mesh) pair.  The ray is read from where MODE 1 parked it,
@@ -1221,6 +1298,7 @@ struct ptx_tracer {
     TileMap tm{};
     int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, grid_seg = 0, cap = 0, cus = 0;
     bool grid_forced = false;                  // PTX_DEBUG_WG_PER_CU given: the grid is what it says for every kernel
+    int dbg_total_wg_per_cu = 0, dbg_nsets = 0; // PTX_DEBUG_TOTAL_WG_PER_CU / PTX_DEBUG_NSETS: tuning experiments (grid of a whole launch; sets of a short run)
     // device memory
     DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
     float *d_image = nullptr; bool own_image = false;
@@ -1240,6 +1318,7 @@ struct ptx_tracer {
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0, bvh_stack = BVH_STACK;
     int mesh_chunks = 1;                                 // see DScene::mesh_chunks
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
+    float *d_ldsblob = nullptr;                          // DScene::ldsblob for the ntri_lds k_bounce is launched with
     uint32_t bump_bits = 0;
     bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
     bool no_fast = false;                                // PTX_DEBUG_NO_FAST: always the general k_bounce (A/B timing, tests of both variants)
@@ -1296,6 +1375,7 @@ struct ptx_tracer {
         s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.bvh_stack = 0; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
         s.fnorm = d_fnorm; s.cnorm = d_cnorm; s.bump_bits = bump_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
+        s.ldsblob = nullptr;               // (set by enqueue_batch together with tri_lds / ntri_lds: the blob is laid out for those)
         return s;
     }
     bool cache_active() const { return opt.cache_first_bounce && !opt.antialiasing && !opt.depth_of_field; }
@@ -1366,7 +1446,7 @@ int free_tracer(ptx_tracer *t) {
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamSynchronize(t->lane_stream[l]);      // work traced ahead
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_ldsblob); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_cache_chunk); hipFree(t->d_cache_super);
@@ -1464,10 +1544,15 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     // ... the split bounce's kernels are many short ones: 16 workgroups per CU (C5 -2 %); everything else 8 as before
     // (traced ahead of per-call requests: two of the seven slots per CU stay free, so that the caller's own short kernels -- gather,
     // preview -- start at once instead of waiting for one of these long-running workgroups to end: 0.53 -> 0.50 ms per call)
-    const int grid = t->grid_forced ? t->grid : std::min(t->grid, t->cus * (fast_unsplit ? (defer ? PT_FAST_WAVES - 2 : PT_FAST_WAVES) : t->split_mesh ? 16 : 8));
+    // The launch's workgroups: one round of the kernel's occupancy over the whole chip, WHATEVER one segment holds (round 3: until
+    // then the total was capped by one segment's tile count, so the K = 10 segments of a 1/8 tile ran as 1010 workgroups of ten
+    // tiles -- 4 per CU -- instead of 1790 of six: 20 steps of such a tile 0.636 -> 0.585 ms, tools/gpu_tile_grid_sweep.py)
+    int grid = t->grid_forced ? t->grid : t->cus * (fast_unsplit ? (defer ? PT_FAST_WAVES - 2 : PT_FAST_WAVES) : t->split_mesh ? 16 : 8);
+    if (t->dbg_total_wg_per_cu > 0) grid = t->cus * t->dbg_total_wg_per_cu;      // tuning experiments
     int gx = grid / K;                               // workgroups per segment
-    if (gx < 64) gx = 64;
+    if (gx < 64 && t->dbg_total_wg_per_cu <= 0) gx = 64;
     if (gx > t->maxTiles) gx = t->maxTiles;
+    if (gx > t->grid_seg) gx = t->grid_seg;
     if (gx > grid) gx = grid;
     if (gx < 1) gx = 1;
     const int nsuper = (gx + 63) / 64;
@@ -1521,6 +1606,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         }
         BounceParams bp;
         bp.sc = t->scene(); bp.sc.tri_lds = t->tri_lds; bp.sc.ntri_lds = t->split_mesh ? 0 : t->ntri_lds; bp.sc.cull = t->cull; bp.cam = t->cam; bp.tm = t->tm;
+        bp.sc.ldsblob = t->d_ldsblob;
         // (split: the mesh search runs in k_mesh from global memory, so the triangle tables need no LDS)
         // bounce b writes its stage into soa[1 - (b & 1)] (bounce 0 of a cache-enabled tracer: into soa[2], kept across
         // iterations) and reads the previous bounce's through that bounce's local index and run tables
@@ -1945,6 +2031,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
     t->no_fast = getenv("PTX_DEBUG_NO_FAST") != nullptr;
     t->force_fast = getenv("PTX_DEBUG_FORCE_FAST") != nullptr;
+    if (const char *e = getenv("PTX_DEBUG_TOTAL_WG_PER_CU")) t->dbg_total_wg_per_cu = std::max(0, atoi(e));
+    if (const char *e = getenv("PTX_DEBUG_NSETS")) t->dbg_nsets = std::max(0, atoi(e));
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
@@ -1994,6 +2082,23 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             }
         }
     }
+    if (t->tri_lds) {   // the scene tables as k_bounce stages them (split: without the triangle tables), in one array: DScene::ldsblob
+        const int nl = t->split_mesh ? 0 : t->ntri_lds;
+        const size_t n9 = (size_t)nl * 9, n15 = (size_t)nl * 15, nm = (size_t)nmaterials * 11, ng = (size_t)ngeoms * GTAB_WORDS, nf = (size_t)nl * 3, nc = (size_t)ngeoms * 18;
+        HC(hipMalloc(&t->d_ldsblob, sizeof(float) * std::max<size_t>(n9 + n15 + nm + ng + nf + nc, 4)));
+        float *o = t->d_ldsblob;
+        if (n9) HC(hipMemcpy(o, t->d_tri9, sizeof(float) * n9, hipMemcpyDeviceToDevice));
+        o += n9;
+        if (n15) HC(hipMemcpy(o, t->d_faces, sizeof(float) * n15, hipMemcpyDeviceToDevice));
+        o += n15;
+        if (nm) HC(hipMemcpy(o, t->d_mats, sizeof(float) * nm, hipMemcpyDeviceToDevice));
+        o += nm;
+        if (ng) HC(hipMemcpy(o, t->d_gtab, sizeof(float) * ng, hipMemcpyDeviceToDevice));
+        o += ng;
+        if (nf) HC(hipMemcpy(o, t->d_fnorm, sizeof(float) * nf, hipMemcpyDeviceToDevice));
+        o += nf;
+        if (nc) HC(hipMemcpy(o, t->d_cnorm, sizeof(float) * nc, hipMemcpyDeviceToDevice));
+    }
     if (opt.apps_variant) {
         HC(hipMalloc(&t->d_albedo, sizeof(float) * 3 * npix));
         HC(hipMemset(t->d_albedo, 0, sizeof(float) * 3 * npix));
@@ -2017,9 +2122,9 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemset(t->d_emit_count, 0, sizeof(int32_t)));
     HC(hipMalloc(&t->d_emit_pix, sizeof(int32_t) * (size_t)t->cap));
     HC(hipMalloc(&t->d_emit_rgb, sizeof(float) * 3 * (size_t)t->cap));
-#ifdef PT_STAMPS
-    HC(hipMalloc(&t->d_stamps, sizeof(unsigned long long) * 32));
-    HC(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * 32));
+#if defined(PT_STAMPS) || defined(PT_WGCLOCK)
+    HC(hipMalloc(&t->d_stamps, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
+    HC(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
 #endif
     HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 65));
     HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 65));
@@ -2092,7 +2197,8 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
         // ... and into TWO sets rather than three while two can hold the call: a one-shot of three sets starts its third
         // late (the host issues the sets one after the other) and makes all of them smaller -- 20 iterations as 10 + 10
         // instead of 7 + 7 + 6: full frame equal, 1/2 tile -2 %, 1/4 and 1/8 tile -7 % (tools/gpu_short_tile_sweep.py)
-        const int nsets = count <= 2 * t->kmax ? std::min(2, t->lanes) : t->lanes;
+        int nsets = count <= 2 * t->kmax ? std::min(2, t->lanes) : t->lanes;
+        if (t->dbg_nsets > 0) nsets = std::min(t->dbg_nsets, t->lanes);
         kb = std::min(t->kmax, std::max(kmin, (count + nsets - 1) / nsets));
     }
     const int nl = (t->lanes > 1 && !t->ktiming && t->capture_bounce < 0 && count > kb) ? t->lanes : 1;
@@ -2458,14 +2564,21 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
     return PTX_OK;
 }
 
-int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out32[32]) {
-    if (!t || !out32) return set_error(PTX_ERR_INVALID, "null argument");
-    memset(out32, 0, sizeof(unsigned long long) * 32);
+int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out48[48]) {
+    if (!t || !out48) return set_error(PTX_ERR_INVALID, "null argument");
+    memset(out48, 0, sizeof(unsigned long long) * 48);
     if (!t->d_stamps) return PTX_OK;
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
-    HIPCHECK(hipMemcpy(out32, t->d_stamps, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
-    HIPCHECK(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * 32));
+    HIPCHECK(hipMemcpy(out48, t->d_stamps, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost));
+    {   // -DPT_WGCLOCK: the per-workgroup wall-clock slots summed per kind into [32..36] (first bounce) and [40..44] (later bounces)
+        std::vector<unsigned long long> w((size_t)2 * 64 * 4096 * 5);
+        HIPCHECK(hipMemcpy(w.data(), t->d_stamps + 48, sizeof(unsigned long long) * w.size(), hipMemcpyDeviceToHost));
+        for (int kind = 0; kind < 2; kind++)
+            for (size_t k = 0; k < (size_t)64 * 4096; k++)
+                for (int f = 0; f < 5; f++) out48[32 + kind * 8 + f] += w[((size_t)kind * 64 * 4096 + k) * 5 + f];
+    }
+    HIPCHECK(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
     return PTX_OK;
 }
 

@@ -49,10 +49,12 @@ def main(tag, d_stats, d_fetch, d_write):
         except Exception:
             pass
     res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
-                   "--no-cpu-baseline; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
-                   "FETCH_SIZE correction (checked in round 1 on k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
+                   "--no-cpu-baseline --no-extra-legs; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
+                   "FETCH_SIZE correction (checked in round 1 on the then k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
                    "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 12 iterations (the default batch at 1080p).")
     json.dump(res, open(os.path.join(out, "traffic_%s.json" % tag), "w"), indent=1)
+    if "c5" not in tag:                                # what bench.py reads
+        json.dump(res, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}))
 
 

@@ -39,11 +39,18 @@ def main(tag):
             d["icache_misses_per_launch"] = g("SQC_ICACHE_MISSES", 0.0)
         m["_derived"] = {a: b for a, b in d.items() if b is not None}
         out[k] = m
+    # rays per launch of the dominant kernel in the profiled command (bench.py scales the instruction counts to its own launches by it)
+    try:
+        line = json.loads(open(os.path.join(ROOT, "gpurun_out", "pmc_%s_a.json" % tag)).read().strip().splitlines()[-1])
+        out["_units_per_launch"] = {line["roofline"]["kernel"]: line["roofline"]["units_per_launch"]}
+    except Exception:
+        pass
     out["_how"] = ("rocprofv3 --pmc <8 counters> per pass (tools/pmc_sq.sh), no tracing, -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
-                   "--no-cpu-baseline; means per launch (a k_bounce launch = 12 iterations of one bounce). SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                   "--no-cpu-baseline --no-extra-legs; means per launch (a k_bounce launch = 12 iterations of one bounce). SQ_WAVE_CYCLES / SQ_WAIT_* / "
                    "SQ_ACTIVE_INST_* count quad-cycles summed over waves.")
     p = os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)
     json.dump(out, open(p, "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "sq_latest.json"), "w"), indent=1, sort_keys=True)      # what bench.py reads
     for k in ("k_bounce", "k_bounce<first>", "k_move"):
         if k in out:
             print(k, json.dumps(out[k]["_derived"]), {c: round(v) for c, v in out[k].items() if not c.startswith("_")})

@@ -6,16 +6,17 @@ set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
+# (--no-extra-legs: the profiled process runs the C4 steps only, not the C5 / per-call legs the plain bench adds)
 # kernels back to back (--lanes 1): per-kernel durations comparable with the hipEvent figures of bench.py's roofline leg
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --lanes 1 > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --lanes 1 --no-extra-legs > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_stats.err
 echo "stats pass done"
 # the default command (three launch sets in flight: kernels overlap, their durations stretch)
 rm -rf $R/gpurun_out/prof_stats2
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats2 -- python3 $R/bench.py > $R/gpurun_out/prof_bench2.json 2> $R/gpurun_out/prof_stats2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats2 -- python3 $R/bench.py --no-extra-legs > $R/gpurun_out/prof_bench2.json 2> $R/gpurun_out/prof_stats2.err
 echo "stats pass (default command) done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > $R/gpurun_out/prof_fetch_bench.json 2> $R/gpurun_out/prof_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof_fetch_bench.json 2> $R/gpurun_out/prof_fetch.err
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --lanes 1 --steps 24 --warmup 12 --no-cpu-baseline --no-extra-legs > /dev/null 2> $R/gpurun_out/prof_write.err
 echo "write pass done"
 cd $R && python3 bench.py > gpurun_out/bench_plain.json 2> gpurun_out/bench_plain.err
 tail -1 gpurun_out/bench_plain.json | cut -c1-300
