@@ -1,0 +1,21 @@
+#!/bin/bash
+# per-kernel durations (rocprofv3 --kernel-trace --stats) of the C5-shaped run for .ab/lib*.so variants: bash tools/ab_c5_profile.sh A B ...
+R=$GRAFT_REPO_ROOT
+cp $R/mygpuraytracer_amd/libmi355x_pathtracer.so /tmp/keep.so
+cd /tmp && export TMPDIR=/tmp
+for v in "$@"; do
+  cp $R/.ab/lib$v.so $R/mygpuraytracer_amd/libmi355x_pathtracer.so
+  rm -rf $R/gpurun_out/c5prof_$v
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c5prof_$v -- python3 $R/tools/gpu_c5_profile.py > $R/gpurun_out/c5prof_$v.log 2>&1
+  echo "== $v"; tail -1 $R/gpurun_out/c5prof_$v.log
+  python3 - <<P
+import csv,glob
+f=max(glob.glob("$R/gpurun_out/c5prof_$v/**/*kernel_stats.csv",recursive=True))
+for r in csv.DictReader(open(f)):
+    n=r["Name"]
+    if "k_bounce" in n or "k_mesh" in n or "k_gather" in n:
+        short=n.split("(")[0].replace("void (anonymous namespace)::","")
+        print("%-40s calls %5s avg_us %9.1f total_ms %8.2f" % (short[:40], r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
+P
+done
+cp /tmp/keep.so $R/mygpuraytracer_amd/libmi355x_pathtracer.so
