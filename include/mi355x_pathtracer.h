@@ -233,6 +233,11 @@ int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_b
  *      ShadeableIntersection 32 B, host arrays in/out, the work runs on the device) --------------------------- */
 int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out10);
 int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32);
+/* computeIntersections (src/pathtrace.cu:261-344) through the functions the bounce kernels really run -- candidate masks from the
+ * world boxes, the tile's (ray, geom) pairs tested by the key functions, 64-bit minimum, winner decoded (split != 0: the three
+ * pieces of the split mesh search, BVH traversal with the stack included) -- where ptx_kat_compute_intersections runs the plain
+ * per-ray loop over all geoms.  PTX_ERR_UNSUPPORTED for a scene that does not take that path (more than 32 geoms, no_cull, ...). */
+int ptx_kat_tile_intersect(ptx_tracer *t, int n, const void *paths44, void *isects32, int split);
 int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void *isects32, void *paths44);
 int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44);             /* all W*H camera rays */
 int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *cos_out,

@@ -168,6 +168,7 @@ def load_library():
     L.ptx_get_kernel_times.restype, L.ptx_get_kernel_times.argtypes = i, [vp, vp, vp]
     L.ptx_kat_geom_test.restype, L.ptx_kat_geom_test.argtypes = i, [vp, i, i, vp, vp]
     L.ptx_kat_compute_intersections.restype, L.ptx_kat_compute_intersections.argtypes = i, [vp, i, vp, vp]
+    L.ptx_kat_tile_intersect.restype, L.ptx_kat_tile_intersect.argtypes = i, [vp, i, vp, vp, i]
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
     L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
     L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
@@ -427,6 +428,56 @@ class Tracer:
         self.trace_depth = scene.trace_depth
         self.iteration = 0
 
+    @classmethod
+    def from_pod(cls, dump, options=None, **opt_kw):
+        """pathtraceInit from plain scene arrays instead of a scene file: ptx_create (include/mi355x_pathtracer.h) with the POD
+        dict `Scene.dump()` returns (geom_ints [type, material, faces], geom_mats [transform, inverse, invTranspose], materials,
+        faces per geom, cam_ints [W, H, iterations, depth], cam_floats, textures {(geom, kd|ks|ke|bump): uint8 HxWxC}) -- the
+        way a caller that holds a loaded `Scene` of the reference (src/scene.h:11-32) hands its vectors over."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        if self.lib.ptx_device_count() < 1:
+            raise PathTracerError("no HIP device is visible; the path tracer has no CPU path")
+        self.options = options if options is not None else default_options(**opt_kw)
+        ng, nm = len(dump["geom_ints"]), len(dump["materials"])
+        geoms = (Geom * max(ng, 1))()
+        keep = []                                           # host arrays the structs point into, until ptx_create has uploaded them
+        trs = dump.get("geom_trs")
+        for i in range(ng):
+            g = geoms[i]
+            g.type, g.materialid = int(dump["geom_ints"][i][0]), int(dump["geom_ints"][i][1])
+            if trs is not None:
+                g.translation[:], g.rotation[:], g.scale[:] = [list(map(float, trs[i][k:k + 3])) for k in (0, 3, 6)]
+            gm = np.ascontiguousarray(dump["geom_mats"][i], np.float32)
+            g.transform[:], g.inverseTransform[:], g.invTranspose[:] = list(gm[:16]), list(gm[16:32]), list(gm[32:48])
+            f = np.ascontiguousarray(dump["faces"][i], np.float32).reshape(-1, 15)
+            keep.append(f)
+            g.faceSize = len(f)
+            g.faces = f.ctypes.data_as(C.POINTER(C.c_float)) if len(f) else None
+            for which, name in enumerate(("kd", "ks", "ke", "bump")):          # checker order: kd, ks, ke, bump
+                img = (dump.get("textures") or {}).get((i, which))
+                if img is not None:
+                    img = np.ascontiguousarray(img, np.uint8)
+                    keep.append(img)
+                    t = getattr(g, name)
+                    t.height, t.width, t.channels = img.shape
+                    t.image = img.ctypes.data_as(C.POINTER(C.c_uint8))
+        mats = (Material * max(nm, 1))()
+        for i in range(nm):
+            C.memmove(C.byref(mats[i]), np.ascontiguousarray(dump["materials"][i], np.float32).ctypes.data, 44)
+        cam = Camera()
+        ci, cf = dump["cam_ints"], [float(v) for v in dump["cam_floats"]]
+        cam.resolution[:] = [int(ci[0]), int(ci[1])]
+        cam.position[:], cam.lookAt[:], cam.view[:], cam.up[:], cam.right[:] = cf[0:3], cf[3:6], cf[6:9], cf[9:12], cf[12:15]
+        cam.fov[:], cam.pixelLength[:] = cf[15:17], cf[17:19]
+        h = vp()
+        _check(self.lib.ptx_create(ng, geoms, nm, mats, C.byref(cam), int(ci[3]), C.byref(self.options), None, None, C.byref(h)), "ptx_create")
+        self.h = h
+        self.width, self.height = int(ci[0]), int(ci[1])
+        self.trace_depth = int(ci[3])
+        self.iteration = 0
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.ptx_destroy(self.h)
@@ -570,6 +621,15 @@ class Tracer:
         out = np.zeros(len(paths), np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4"),
                                              ("texcoord", "<f4", 2), ("geomId", "<i4")]))
         _check(self.lib.ptx_kat_compute_intersections(self.h, len(paths), _ptr(paths), _ptr(out)), "ptx_kat_compute_intersections")
+        return out
+
+    def tile_intersect(self, paths, split=False):
+        """computeIntersections through the production functions (cullMask, primKey / meshKey, decodeKey): ptx_kat_tile_intersect"""
+        paths = np.ascontiguousarray(paths)
+        assert paths.dtype.itemsize == 44
+        out = np.zeros(len(paths), np.dtype([("t", "<f4"), ("normal", "<f4", 3), ("materialId", "<i4"),
+                                             ("texcoord", "<f4", 2), ("geomId", "<i4")]))
+        _check(self.lib.ptx_kat_tile_intersect(self.h, len(paths), _ptr(paths), _ptr(out), 1 if split else 0), "ptx_kat_tile_intersect")
         return out
 
     def shade(self, iteration, idx, isects, paths):

@@ -1223,6 +1223,54 @@ __global__ void k_kat_intersect(DScene sc, int n, const HostPath *paths, HostIse
     out[i] = o;
 }
 
+// computeIntersections as PRODUCTION runs it, on arbitrary rays: candidate masks from the world boxes (cullMask), the tile's (ray, geom)
+// pairs pooled in LDS and tested by primKey / meshKey, 64-bit LDS minimum, winner decoded by decodeKey -- tileIntersect itself, with
+// the scene tables staged as k_bounce stages them.  SPLIT: the three pieces of the split mesh search instead -- tileIntersect<DEFER>
+// (pass 1), meshKey with the front-to-back stack traversal per (ray, mesh) candidate folded in by minimum (k_mesh), decodeKey (pass 2).
+// A named test for the functions that the frame-level parity tests only reach through whole bounces.
+template <bool SPLIT>
+__global__ __launch_bounds__(TILE) void k_kat_tile(DScene sc, DScene scg, int n, const HostPath *paths, HostIsect *out, int uses_uv) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *lds = pt_lds + sceneLdsWords(sc);
+    int32_t *tcnt = lds;                                             // [8] (the rest of the head is unused here)
+    int32_t *rec = lds + ldsHeadWords(1);
+    int32_t *stack = rec + REC_WORDS;                                // SPLIT: [bvh_stack][TILE]
+    stageSceneToLds(sc, tid, TILE);
+    if (tid < 8) tcnt[tid] = 0;
+    __syncthreads();
+    int tq = 0;
+    const float *gtab_lds = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11;
+    for (int base = blockIdx.x * TILE; base < n; base += gridDim.x * TILE) {
+        const int i = base + tid;
+        const bool alive = i < n;
+        Ray ray; ray.o = ray.d = V3(0.f, 0.f, 0.f);
+        if (alive) { ray.o = ld3(paths[i].o); ray.d = ld3(paths[i].d); }
+        Hit h;
+        h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = h.v = 0.f; h.geom = 0; h.mat = 0;
+        unsigned long long key = KEY_NONE;
+        uint32_t mesh_cand = 0;
+        if (!SPLIT) {
+            tileIntersect<false>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand);
+        } else {
+            tileIntersect<true>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand);
+            for (uint32_t m = mesh_cand; m; m &= m - 1) {
+                const unsigned long long k = meshKey(scg, scg.gtab, __ffs((int)m) - 1, ray, -1, stack + tid, TILE);
+                key = k < key ? k : key;
+            }
+            if (alive) decodeKey(sc, gtab_lds, key, ray, uses_uv != 0, h);
+        }
+        if (alive) {
+            HostIsect o;
+            memset(&o, 0, sizeof o);
+            if (h.t > 0.f) { o.t = h.t; o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z; o.materialId = h.mat; o.uv[0] = h.u; o.uv[1] = h.v; o.geomId = h.geom; }
+            else o.t = -1.f;
+            out[i] = o;
+        }
+        __syncthreads();                                             // (tileIntersect's scratch is reused by the next tile)
+        __syncthreads();
+    }
+}
+
 // shadeFakeMaterial in full (src/pathtrace.cu:365-403), one path per thread, idx[] = RNG stream indices
 __global__ void k_kat_shade(DScene sc, int iter, int n, const int32_t *idx, const HostIsect *isects, HostPath *paths) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2442,6 +2490,32 @@ int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, voi
     HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_kat_intersect, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), n, d_p, d_i);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(d_p); hipFree(d_i);
+    return PTX_OK;
+}
+
+int ptx_kat_tile_intersect(ptx_tracer *t, int n, const void *paths44, void *isects32, int split) {
+    KAT_PROLOGUE
+    if (n <= 0) return PTX_OK;
+    if (!t->cull || !t->tri_lds) return set_error(PTX_ERR_UNSUPPORTED, "this scene does not take the tile path (candidate masks / LDS tables are off)");
+    if (split && !t->d_bvh_root) return set_error(PTX_ERR_UNSUPPORTED, "no mesh of this scene has a BVH: nothing for the split mesh search to do");
+    HostPath *d_p = nullptr; HostIsect *d_i = nullptr;
+    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
+    HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
+    // the scene as enqueue_batch hands it to k_bounce (tables staged; split: without the triangle tables) and as k_mesh gets it
+    DScene sc = t->scene();
+    sc.tri_lds = t->tri_lds; sc.ntri_lds = (split || t->split_mesh) ? 0 : t->ntri_lds; sc.cull = t->cull;
+    sc.ldsblob = (split || t->split_mesh) == t->split_mesh ? t->d_ldsblob : nullptr;      // (the blob is laid out for the tracer's own choice)
+    DScene scg = t->scene();
+    scg.bvh_stack = t->bvh_stack;
+    const size_t lds = sizeof(int32_t) * (bounceLdsWords(sceneTableWords(sc.ntri_lds, t->nmats, t->ngeoms), 1) + (split ? (size_t)t->bvh_stack * TILE : 0));
+    const dim3 grid((unsigned)std::min(1024, (n + TILE - 1) / TILE));
+    if (split) hipLaunchKernelGGL(k_kat_tile<true>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
+    else hipLaunchKernelGGL(k_kat_tile<false>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
     hipFree(d_p); hipFree(d_i);

@@ -260,12 +260,69 @@ def png_files(so):
     print("png_files.npz:", len(out), "files")
 
 
+def cottage_text(res=(96, 54), depth=6):
+    """the reference's cornellObj.txt with its cube swapped for its models/cottage_obj.obj (32 triangles + 227 quads = 486
+    triangles, the one real mesh the reference ships besides the cube), scaled into the box"""
+    text = open(os.path.join(REFERENCE_ROOT, "scenes", "cornellObj.txt")).read()
+    assert "../models/cube.obj" in text
+    text = text.replace("../models/cube.obj", "../models/cottage_obj.obj")
+    head, _ = text.rsplit("TRANS", 1)
+    return scene_text_with(head + "TRANS       0.5 1.2 0\nROTAT       0 30 0\nSCALE       .02 .02 .02\n", res, depth)
+
+
+def cottage(R):
+    """The cottage scene as VECTORS: what the reference's loader made of it (geoms, 486 x 15 face floats, materials, camera), the
+    reference's meshIntersectionTest on rays around it, and a small render by the restated loop -- so that the GPU tier, which
+    cannot read /root/reference, builds the scene from arrays (ptx_create) and is checked on a second real mesh."""
+    rng = np.random.default_rng(20261005)
+    R.load_text(cottage_text())
+    d = R.dump()
+    R.apply_runcuda_camera()
+    out = dict(geom_ints=d["geom_ints"], geom_trs=d["geom_trs"], geom_mats=d["geom_mats"], materials=d["materials"],
+               cam_ints=d["cam_ints"], cam_floats=d["cam_floats"], cam_floats_runcuda=R.dump()["cam_floats"],
+               cam_floats_1080p=d["cam_floats"], texture_vector_sizes=d["texture_vector_sizes"])
+    for gi, f in enumerate(d["faces"]):
+        out["faces_%d" % gi] = f
+    np.savez_compressed(os.path.join(HERE, "loader_cottage.npz"), **out)
+    gi = [k for k in range(len(d["geom_ints"])) if len(d["faces"][k])][0]
+    rays = random_rays(rng, 2048, d["geom_trs"][gi][:3].astype(np.float64) + [0, 1.0, 0], 2.5)
+    np.savez_compressed(os.path.join(HERE, "isect_kat_cottage.npz"), **{"rays_%d" % gi: rays, "out_%d" % gi: R.geom_test(gi, rays)})
+    R.set_options(aa=1, dof=0, sort=1, cache=1)
+    R.pt_init()
+    out = dict(options=np.array([1, 0, 1, 1], np.int32))
+    for it in (1, 2, 3, 4):
+        if it == 1:
+            R.pt_generate(1)
+            b = 0
+            while True:
+                n = R.num_paths()
+                R.pt_bounce(1, 3)
+                out["stream_pix_b%d" % b] = R.paths()["pixelIndex"][:n].copy()
+                out["stream_mat_b%d" % b] = R.isects()["materialId"][:n].copy()
+                out["stream_t_b%d" % b] = R.isects()["t"][:n].copy()
+                if R.pt_bounce(1, 12) == 0:
+                    break
+                b += 1
+            R.pt_final_gather()
+        else:
+            R.iterate(it)
+        if it in (1, 4):
+            out["image_spp%d" % it] = R.image()
+            out["counts_it%d" % it] = R.live_counts()
+    np.savez_compressed(os.path.join(HERE, "render_cottage.npz"), **out)
+    print("cottage: geom", gi, "faces", len(d["faces"][gi]), "hits", int((R.geom_test(gi, rays)[:, 0] > 0).sum()), "of", len(rays),
+          "counts", out["counts_it1"].tolist())
+
+
 def main():
     so = build_ref()
     if not so:
         sys.exit("oracle/_ref/libptref.so cannot be built here (no /root/reference)")
     if sys.argv[1:] in (["hdr"], ["png"]):           # only this fixture (the others are unchanged by it)
         (hdr_files if sys.argv[1] == "hdr" else png_files)(so)
+        return
+    if sys.argv[1:] == ["cottage"]:
+        cottage(RefLib(so))
         return
     R = RefLib(so)
     rng = np.random.default_rng(20261004)
@@ -417,6 +474,7 @@ def main():
     png_textures(R)
     jpeg_textures(R)
     ngon_faces(R)
+    cottage(R)
     hdr_files(so)
     png_files(so)
     print("golden fixtures written to", HERE)

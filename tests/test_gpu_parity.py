@@ -163,7 +163,13 @@ def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
     """The permutation is the observable: after each bounce the device stream holds exactly the reference's sorted
     survivors -- same pixels in the same order, same RNG stream index, same ray / colour / hit bits."""
     s, T = make_pair(gpu_product, O, scene, res, depth, **opt)
-    mats = s.dump()["materials"]
+    check_sorted_streams(T, O, s.dump(), depth)
+    T.close()
+
+
+def check_sorted_streams(T, O, d, depth):
+    """d = the scene's POD dict (Scene.dump() layout)"""
+    mats = d["materials"]
     it = 1
     for bounce in range(min(depth - 1, 5)):
         T.reset_image()
@@ -188,10 +194,119 @@ def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
             assert beq(g[nm], paths["color"][pend][:, k])
         for k, nm in enumerate(("nx", "ny", "nz")):
             assert beq(g[nm], isects["normal"][pend][:, k])
-        if s.dump()["textures"]:                                   # texcoords travel only when some texture exists
-            obj = s.dump()["geom_ints"][isects["geomId"][pend], 0] == 3
+        if d.get("textures"):                                      # texcoords travel only when some texture exists
+            obj = d["geom_ints"][isects["geomId"][pend], 0] == 3
             assert beq(g["u"][obj], isects["texcoord"][pend][obj, 0]) and beq(g["v"][obj], isects["texcoord"][pend][obj, 1])
+
+
+def test_cottage_mesh_from_vectors_on_device(gpu_product, O):
+    """SURVEY 8(f)-3 on the GPU without shipping the file: the reference's models/cottage_obj.obj (486 triangles) as the REFERENCE
+    LOADER returned it (tests/golden/loader_cottage.npz: geoms, 486 x 15 face floats, materials, camera) goes through ptx_create
+    as plain arrays (Tracer.from_pod), with the BVH + split mesh search, fused, and with the reference's loop over all faces:
+    meshIntersectionTest's golden rays, the sorted stream after every bounce, image and ray counts after 1 and 4 iterations --
+    against the oracle on the same arrays bit for bit, and against what the reference build rendered (render_cottage.npz)."""
+    from conftest import dump_from_golden
+    g, r, k = golden("loader_cottage.npz"), golden("render_cottage.npz"), golden("isect_kat_cottage.npz")
+    d = dump_from_golden(g, cam="cam_floats_runcuda")
+    depth = int(d["cam_ints"][3])
+    for opt in ({}, dict(no_mesh_split=1), dict(no_bvh=1)):
+        O.set_libm(1)
+        O.create(d, {})
+        O.set_options(aa=1, dof=0, sort=1, cache=1)
+        O.pt_init()
+        with gpu_product.Tracer.from_pod(d, **opt) as T:
+            gi = [int(x[5:]) for x in k.files if x.startswith("rays_")][0]
+            out, ref = T.geom_test(gi, k["rays_%d" % gi]), k["out_%d" % gi]
+            hit = ref[:, 0] > 0
+            assert hit.sum() > 200 and beq(out[:, 0], ref[:, 0]) and beq(out[hit], ref[hit])
+            check_sorted_streams(T, O, d, depth)
+            T.reset_image(); T.debug_capture(-1)
+            O.pt_init()
+            for it in range(1, 5):
+                O.iterate(it); T.pathtrace(it)
+                if it in (1, 4):
+                    img = T.read_image()
+                    assert beq(img, O.image()) and np.array_equal(img, r["image_spp%d" % it])
+                    assert T.stats()["rays_per_bounce"][:depth] == r["counts_it%d" % it].tolist()
+
+
+def _kat_paths(rays):
+    p = np.zeros(len(rays), PATH_DTYPE)
+    p["origin"], p["direction"] = rays[:, :3], rays[:, 3:6]
+    p["color"] = 1.0
+    p["pixelIndex"] = np.arange(len(rays)); p["remainingBounces"] = 4
+    return p
+
+
+@pytest.mark.parametrize("scene,fixture,opt,split", [
+    ("cornellGlass.txt", "cornellGlass", {}, False), ("cornellObj.txt", "cornellObj", {}, False),
+    ("cornellSpaceship.txt", "cornellSpaceship", {}, True), ("cornellSpaceship.txt", "cornellSpaceship", dict(no_mesh_split=1), False),
+    ("cornellSpaceship.txt", "cornellSpaceship", dict(no_bvh=1), False), (None, "cottage", {}, True), (None, "cottage", dict(no_mesh_split=1), False)])
+def test_production_intersect_on_the_golden_rays(gpu_product, O, scene, fixture, opt, split):
+    """The functions the bounce kernels intersect with -- cullMask -> pair lists -> primKey / meshKey -> 64-bit minimum ->
+    decodeKey (tileIntersect), and for BVH scenes the split search's pass 1 / stack traversal / pass 2 -- get a test of their own
+    (ptx_kat_tile_intersect): on the rays of the per-geom golden vectors, all geoms' rays in one batch, the nearest hit over the whole
+    scene equals the oracle's computeIntersections bit for bit, and wherever the winner is the geom a ray set was made for, distance,
+    normal and texcoords are the REFERENCE's own box / sphere / meshIntersectionTest outputs (isect_kat_*.npz, [direct])."""
+    from conftest import dump_from_golden
+    k = golden("isect_kat_%s.npz" % fixture)
+    if scene:
+        s, T = make_pair(gpu_product, O, scene, (16, 16), 8, **opt)
+        d = s.dump()
+    else:
+        d = dump_from_golden(golden("loader_%s.npz" % fixture), cam="cam_floats_runcuda")
+        O.set_libm(1); O.create(d, {}); O.pt_init()
+        T = gpu_product.Tracer.from_pod(d, **opt)
+    sets = sorted(int(x[5:]) for x in k.files if x.startswith("rays_"))
+    rays = np.concatenate([k["rays_%d" % gi] for gi in sets])
+    p = _kat_paths(rays)
+    got, want = T.tile_intersect(p, split=split), O.compute_intersections(p)
+    hit = want["t"] > 0
+    assert hit.sum() > 100 and beq(got["t"], want["t"])
+    # (texcoords travel only when the scene has a texture to look up with them: DESIGN 4)
+    for f in ("normal", "materialId", "geomId") + (("texcoord",) if d.get("textures") else ()):
+        assert beq(got[f][hit], want[f][hit]), f
+    assert beq(T.compute_intersections(p)["t"], want["t"])           # (the plain loop, for completeness)
+    off = 0
+    pinned = 0
+    for gi in sets:
+        ref = k["out_%d" % gi]
+        sl = got[off:off + len(ref)]
+        mine = (sl["t"] > 0) & (sl["geomId"] == gi)
+        assert beq(sl["t"][mine], ref[mine, 0]) and beq(sl["normal"][mine], ref[mine, 4:7])
+        if d["geom_ints"][gi][0] == 3 and d.get("textures"):
+            assert beq(sl["texcoord"][mine], ref[mine, 7:9])
+        pinned += int(mine.sum())
+        off += len(ref)
+    # (the cottage is scaled by 0.02 and the reference compares a mesh's OBJECT-space distance with the other geoms' world-space ones
+    # -- src/intersections.h:233, SURVEY 8(a9) -- so a wall 5 units away beats the roof 2 units away: few rays keep the mesh)
+    assert pinned > (100 if fixture != "cottage" else 0)
     T.close()
+
+
+def test_full_size_c5_tile_of_an_8_way_split_against_oracle(gpu_product, O):
+    """BASELINE configs[4] names 8 GPUs: what ONE rank of that run computes -- its interleaved 8-row blocks of the 3840x2160 frame of
+    the textured-mesh scene with depth of field, split mesh search and BVH on a tile of owned rows -- against the oracle restricted
+    to the same rows (its loop over all faces; 16 threads): identical partial frame, foreign rows zero, identical ray counts."""
+    from mygpuraytracer_amd import multigpu
+    rank = 5
+    s, T = make_pair(gpu_product, O, "cornellSpaceship.txt", (3840, 2160), 8, depth_of_field=1, tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=8)
+    O.set_tile(multigpu.TILE_ROWS, rank, 8); O.pt_init()
+    try:
+        assert T.owned_pixels() == O.pixelcount()
+        O.set_threads(16)
+        for it in range(1, 4):
+            O.iterate(it)
+        T.render(1, 3)
+        img = T.read_image()
+        assert beq(img, O.image())
+        assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
+        mine = np.repeat((np.arange(2160) // multigpu.TILE_ROWS) % 8 == rank, 3840)
+        assert not img[~mine].any() and img[mine].any()
+    finally:
+        O.set_threads(1)
+        O.set_tile(0, 0, 1)
+        T.close()
 
 
 RENDER_CASES = [

@@ -46,9 +46,10 @@ def test_loader_arithmetic(O, scene):
     assert np.allclose(O.cam_floats[:3], [0, 4.99999952, 10.5], atol=1e-6)
 
 
-@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj", "cornellSpaceship"])
+@pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj", "cornellSpaceship", "cottage"])
 def test_intersection_kats(O, scene):
-    """boxIntersectionTest / sphereIntersectionTest / meshIntersectionTest on 1024 rays per geom."""
+    """boxIntersectionTest / sphereIntersectionTest / meshIntersectionTest on 1024 rays per geom (cottage: the reference's own
+    486-triangle models/cottage_obj.obj as the reference's loader returned it, 2048 rays around it)."""
     g = golden("loader_%s.npz" % scene)
     k = golden("isect_kat_%s.npz" % scene)
     O.create(dump_from_golden(g))
@@ -94,6 +95,33 @@ def test_shade_kats(O, tag):
 
 
 RENDERS = ["c1_sphere", "c2_cornell_cache", "c3_glass", "c4_obj", "c5_dof", "nosort_obj", "mirror20", "c5_ship"]
+
+
+def test_cottage_render(O):
+    """The cottage scene from its vector fixture (loader_cottage.npz: the reference loader's geoms, faces, materials, camera at
+    96x54 depth 6): sorted streams of iteration 1, image and counts after 1 and 4 iterations as the reference build gave them."""
+    g, r = golden("loader_cottage.npz"), golden("render_cottage.npz")
+    O.create(dump_from_golden(g, cam="cam_floats"))
+    O.apply_runcuda_camera()
+    assert beq(O.cam_floats, g["cam_floats_runcuda"])
+    O.set_options(aa=1, dof=0, sort=1, cache=1)
+    O.pt_init()
+    O.pt_generate(1)
+    b = 0
+    while True:
+        n = O.num_paths()
+        O.pt_bounce(1, 3)
+        assert beq(O.paths()["pixelIndex"][:n], r["stream_pix_b%d" % b])
+        assert beq(O.isects()["materialId"][:n], r["stream_mat_b%d" % b])
+        assert beq(O.isects()["t"][:n], r["stream_t_b%d" % b])
+        if O.pt_bounce(1, 12) == 0:
+            break
+        b += 1
+    O.pt_final_gather()
+    assert beq(O.image(), r["image_spp1"]) and beq(O.live_counts(), r["counts_it1"])
+    for it in (2, 3, 4):
+        O.iterate(it)
+    assert beq(O.image(), r["image_spp4"]) and beq(O.live_counts(), r["counts_it4"])
 RENDER_SCENE = dict(c1_sphere=("sphere", (64, 64), 4), c2_cornell_cache=("cornell", (64, 64), 8), c3_glass=("cornellGlass", (96, 54), 12),
                     c4_obj=("cornellObj", (96, 54), 8), c5_dof=("cornellGlass", (96, 54), 8), nosort_obj=("cornellObj", (96, 54), 8),
                     c5_ship=("cornellSpaceship", (96, 54), 8))
