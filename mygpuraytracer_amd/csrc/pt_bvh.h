@@ -52,6 +52,7 @@ namespace ptd {
 struct BvhBuild {
     std::vector<BvhQuad> nodes;           // 2 per node, appended to whatever is already there
     std::vector<float> tris;              // 16 per leaf triangle, appended likewise
+    std::vector<BvhWide4> wide;           // 4 per four-wide quantised node = 16 words (bvhNearestWide), appended likewise
 };
 
 namespace bvh_detail {
@@ -140,7 +141,10 @@ inline int buildRec(std::vector<Prim> &pr, std::vector<Node> &out, int a, int b,
 
 // Appends the tree of faces [faceStart, faceStart + faceCount) (15 floats each: 3 x (pos xyz, uv)) to `out`;
 // tri9 holds v0, e1, e2 per face as uploaded for the plain loop.  Returns the root's node index (and the tree's depth).
-inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int faceCount, BvhBuild &out, int *depth_out = nullptr) {
+// wroot_out / wneed_out: the tree's four-wide root (index into out.wide / 8; -1 if the root is a leaf) and the stack entries a walk of
+// the wide nodes can need (3 per level below the root + 1).
+inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int faceCount, BvhBuild &out, int *depth_out = nullptr,
+                    int *wroot_out = nullptr, int *wneed_out = nullptr) {
     using namespace bvh_detail;
     std::vector<Prim> pr((size_t)faceCount);
     for (int j = 0; j < faceCount; j++) {
@@ -168,6 +172,7 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
     std::vector<int> skip(tree.size(), -1);
     for (size_t i = 0; i < tree.size(); i++)
         if (tree[i].count == 0) { skip[tree[i].left] = base + tree[i].right; skip[tree[i].right] = skip[i]; }
+    std::vector<float> flo(tree.size() * 3), fhi(tree.size() * 3);      // the boxes as stored (inflated, rounded outwards)
     for (size_t i = 0; i < tree.size(); i++) {
         const Node &nd = tree[i];
         double diag = 0.0;
@@ -178,11 +183,89 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
             lo[k] = nextafterf((float)(nd.lo[k] - m), -INFINITY);
             hi[k] = nextafterf((float)(nd.hi[k] + m), INFINITY);
         }
+        for (int k = 0; k < 3; k++) { flo[i * 3 + k] = lo[k]; fhi[i * 3 + k] = hi[k]; }
         BvhQuad A{lo[0], lo[1], lo[2], skip[i]};
         // leaf: count << 28 | first triangle; inner node: its right child (count bits 0) -- the left child is n + 1, so a visit
         // can request both children's boxes at once instead of learning the right child from the left child's skip link
         BvhQuad B{hi[0], hi[1], hi[2], nd.count ? (int32_t)(((uint32_t)nd.count << 28) | (uint32_t)(tbase + nd.first)) : (int32_t)(base + nd.right)};
         out.nodes[2 * (base + i)] = A; out.nodes[2 * (base + i) + 1] = B;
+    }
+    // Four-wide quantised nodes over the same tree (layout and walk: bvhNearestWide in pt_device.h): a wide node per inner node
+    // reached in an even number of steps from the root; its entries are that node's grandchildren, or a child where the child is a
+    // leaf (leaves first), each with the binary node's own stored box rounded OUTWARDS onto the wide node's 8-bit grid.
+    {
+        const int wbase = (int)(out.wide.size() / 4);
+        auto alloc = [&]() { out.wide.resize(out.wide.size() + 4); return (int)(out.wide.size() / 4) - 1; };
+        auto bits = [](float f) { int32_t v; memcpy(&v, &f, 4); return v; };
+        int wroot = -1;
+        if (tree[0].count == 0 && tbase + faceCount < (1 << 24)) {
+            wroot = alloc();
+            std::vector<int> level{0}, wide_of{wroot};
+            for (size_t q = 0; q < level.size(); q++) {
+                const int i = level[q], w = wide_of[q];
+                int ent[4], ne = 0;
+                for (int pass = 0; pass < 2; pass++)                     // leaves into the first slots
+                    for (int c : {tree[i].left, tree[i].right}) {
+                        if (tree[c].count) { if (pass == 0) ent[ne++] = c; }
+                        else for (int g : {tree[c].left, tree[c].right})
+                            if ((tree[g].count != 0) == (pass == 0)) ent[ne++] = g;
+                    }
+                // the grid: origin = the entries' common lower corner, step = extent / 255 rounded up until 255 steps reach the top
+                float org[3], step[3];
+                for (int k = 0; k < 3; k++) {
+                    float lo = INFINITY, hi = -INFINITY;
+                    for (int e = 0; e < ne; e++) { lo = std::min(lo, flo[ent[e] * 3 + k]); hi = std::max(hi, fhi[ent[e] * 3 + k]); }
+                    org[k] = lo;
+                    float st = (hi - lo) / 255.0f;
+                    if (!(st > 0.0f)) st = 1e-30f;
+                    while (fmaf(255.0f, st, lo) < hi) st = nextafterf(st, INFINITY);
+                    step[k] = st;
+                }
+                uint32_t ql[3] = {0, 0, 0}, qh[3] = {0, 0, 0};
+                int32_t ref[4] = {-1, -1, -1, -1};
+                for (int e = 0; e < ne; e++) {
+                    const int b = ent[e];
+                    for (int k = 0; k < 3; k++) {
+                        // largest grid coordinate whose point is <= the box's lower bound / smallest whose point is >= its upper
+                        // bound, decided with the arithmetic the walk uses (one fused multiply-add)
+                        int a = (int)floorf((flo[b * 3 + k] - org[k]) / step[k]);
+                        a = std::min(255, std::max(0, a));
+                        while (a > 0 && fmaf((float)a, step[k], org[k]) > flo[b * 3 + k]) a--;
+                        int z = (int)ceilf((fhi[b * 3 + k] - org[k]) / step[k]);
+                        z = std::min(255, std::max(0, z));
+                        while (z < 255 && fmaf((float)z, step[k], org[k]) < fhi[b * 3 + k]) z++;
+                        // (a = 0 gives the origin itself, <= every lower bound; z = 255 reaches the top by the choice of step)
+                        ql[k] |= (uint32_t)a << (8 * e); qh[k] |= (uint32_t)z << (8 * e);
+                    }
+                    if (tree[b].count) ref[e] = (int32_t)(0x80000000u | ((uint32_t)tree[b].count << 24) | (uint32_t)(tbase + tree[b].first));
+                    else {
+                        const int cw = alloc();
+                        ref[e] = cw;
+                        level.push_back(b); wide_of.push_back(cw);
+                    }
+                }
+                BvhWide4 *W = &out.wide[(size_t)w * 4];
+                W[0] = BvhWide4{bits(org[0]), bits(org[1]), bits(org[2]), bits(step[0])};
+                W[1] = BvhWide4{bits(step[1]), bits(step[2]), ref[0], ref[1]};
+                W[2] = BvhWide4{ref[2], ref[3], (int32_t)ql[0], (int32_t)ql[1]};
+                W[3] = BvhWide4{(int32_t)ql[2], (int32_t)qh[0], (int32_t)qh[1], (int32_t)qh[2]};
+            }
+        }
+        // the stack a walk can need, exactly: descending from a wide node into one inner entry leaves at most its other inner entries
+        // on the stack -- need(w) = max over inner entries c of (inner entries of w - 1) + need(c); wide nodes were created parents
+        // first, so a sweep from the back sees every child before its parent
+        const int nw = (int)(out.wide.size() / 4) - wbase;
+        std::vector<int> need((size_t)std::max(nw, 1), 0);
+        for (int w = nw - 1; w >= 0; w--) {
+            const BvhWide4 *W = &out.wide[(size_t)(wbase + w) * 4];
+            const int32_t refs[4] = {W[1].c, W[1].d, W[2].a, W[2].b};
+            int inner = 0, deepest = 0;
+            for (int k = 0; k < 4; k++)
+                if (refs[k] >= 0) { inner++; deepest = std::max(deepest, need[(size_t)(refs[k] - wbase)]); }
+            need[(size_t)w] = inner ? inner - 1 + deepest : 0;
+        }
+        if (wroot_out) *wroot_out = wroot;
+        if (wneed_out) *wneed_out = (nw ? need[0] : 0) + 1;
     }
     out.tris.resize(out.tris.size() + (size_t)faceCount * 16);
     for (int i = 0; i < faceCount; i++) {

@@ -200,6 +200,7 @@ struct DCamera {                        // = struct Camera, src/sceneStructs.h:8
     float position[3], lookAt[3], view[3], up[3], right[3], fov[2], pixelLength[2];
 };
 struct alignas(16) BvhQuad { float x, y, z; int32_t w; };
+struct alignas(16) BvhWide4 { int32_t a, b, c, d; };     // a quarter of a four-wide quantised node (16 words, bvhNearestWide)
 #ifndef PT_MESH_CHUNK
 #define PT_MESH_CHUNK 4
 #endif
@@ -238,6 +239,9 @@ struct DScene {
     const int32_t *__restrict__ bvh_depth;          // per geom: depth of its tree (root = 0)
     int32_t bvh_stack;                              // entries per lane of the traversal stack the launch provides (k_mesh): trees of
                                                     // depth >= this use the skip links
+    const BvhWide4 *__restrict__ bvh_wide;          // four-wide quantised nodes (4 x 16 B = one 64-byte line each) of the same trees, or NULL
+    const int32_t *__restrict__ bvh_wroot;          // per geom: its wide root, -1 = none
+    const int32_t *__restrict__ bvh_wneed;          // per geom: stack entries the wide walk of its tree can need
     const float *__restrict__ fnorm;    // 3 floats per face: its world-space geometric normal, computed at upload with the
                                         // arithmetic of meshIntersectionTest (src/intersections.h:237-243) -- used when the
                                         // geom has no bump map; cnorm: 18 floats per geom, the six face normals of a cube
@@ -438,6 +442,8 @@ PT_DEV uint32_t texel(const DScene &sc, const DTex &t, int pixelID, int c) {
 }
 
 PT_HD vec3 ld3(const float *__restrict__ p) { return V3(p[0], p[1], p[2]); }
+PT_HD float __int_as_float_hd(int v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
+PT_HD int __float_as_int_hd(float f) { int v; __builtin_memcpy(&v, &f, 4); return v; }
 
 // One triangle of glm::intersectRayTriangle (glm/gtx/intersect.inl:37-74, single sided: a < epsilon => miss) with
 // e1 = v1 - v0 and e2 = v2 - v0 taken from the upload-time table.
@@ -600,13 +606,104 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
     }
 }
 
+// The same search over FOUR-WIDE, QUANTISED nodes (round 3).  Every inner node of the binary tree that is reached in an even number
+// of steps from the root gets a wide node holding its (up to four) grandchildren -- or a child, where that child is a leaf.  A wide
+// node is ONE 64-byte line: origin xyz, step xyz (floats), four references, and the entries' boxes as 8-bit grid coordinates
+// (lo and hi per axis, four entries per 32-bit word): entry box = origin + step * q.  k_mesh walks one tree per lane, every lane
+// somewhere else: its time is the number of cache lines its lanes pull through the CU's L1 (binary walk: two children = 64 B per
+// level; four full-precision boxes per node brought only 11 %), so a node that costs one line per TWO levels is what pays.
+// The grid boxes are rounded OUTWARDS, with the very fused multiply-add the device evaluates them with (pt_bvh.h checks every one),
+// so each contains the binary node's stored (inflated) box: the skip rule -- slabEntry on a box that contains the subtree -- and with
+// it the argument of pt_bvh.h hold unchanged; the per-triangle arithmetic and the (distance, face) minimum are the same, the answer
+// is the same (checked against the loop and the two binary walks on every ray of tests/test_bvh.py).  Reference word: -1 = empty
+// slot, bit 31 set = leaf (count << 24 | first triangle in the low 31 bits), else the entry's own wide node.  Leaves of a node are
+// intersected before its inner entries are ranked, so that what they find prunes their siblings; the inner entries that are hit
+// are visited nearest first, the others pushed farthest first.  `nodes` / `root`: the binary tree, for the root box and the slack.
+PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__restrict__ wide, const float *__restrict__ tris, int root,
+                           int wroot, vec3 o, vec3 d, int &face, float &b0o, float &b1o, int32_t *stack, int stride, int *visited = nullptr) {
+    const RaySlab rs = makeRaySlab(o, d, bvhSlack(nodes[2 * root], nodes[2 * root + 1], o));
+    float tmin = 3.402823466e+38f;
+    face = -1; b0o = 0.f; b1o = 0.f;
+    {
+        float tn;
+        if (visited) ++*visited;
+        if (!slabEntry(nodes[2 * root], nodes[2 * root + 1], rs, tmin, tn)) return tmin;
+    }
+    int sp = 0, n = wroot;
+    for (;;) {
+        const BvhWide4 *W = wide + (size_t)n * 4;
+        const BvhWide4 Q0 = W[0], Q1 = W[1], Q2 = W[2], Q3 = W[3];     // one 64-byte line
+        if (visited) *visited += 4;
+        const float ox = __int_as_float_hd(Q0.a), oy = __int_as_float_hd(Q0.b), oz = __int_as_float_hd(Q0.c);
+        const float sx = __int_as_float_hd(Q0.d), sy = __int_as_float_hd(Q1.a), sz = __int_as_float_hd(Q1.b);
+        const int r0 = Q1.c, r1 = Q1.d, r2 = Q2.a, r3 = Q2.b;
+        const uint32_t lx = (uint32_t)Q2.c, ly = (uint32_t)Q2.d, lz = (uint32_t)Q3.a, hx = (uint32_t)Q3.b, hy = (uint32_t)Q3.c, hz = (uint32_t)Q3.d;
+        float t0 = 3.402823466e+38f, t1 = t0, t2 = t0, t3 = t0;
+        int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+#define PT_WIDE_ENTRY(K, REF, TK, CK)                                                                                          \
+        if (REF != -1) {                                                                                                       \
+            BvhQuad A, B;                                                                                                      \
+            A.x = __builtin_fmaf((float)((lx >> (8 * K)) & 255u), sx, ox); B.x = __builtin_fmaf((float)((hx >> (8 * K)) & 255u), sx, ox); \
+            A.y = __builtin_fmaf((float)((ly >> (8 * K)) & 255u), sy, oy); B.y = __builtin_fmaf((float)((hy >> (8 * K)) & 255u), sy, oy); \
+            A.z = __builtin_fmaf((float)((lz >> (8 * K)) & 255u), sz, oz); B.z = __builtin_fmaf((float)((hz >> (8 * K)) & 255u), sz, oz); \
+            A.w = B.w = 0;                                                                                                     \
+            float tn;                                                                                                          \
+            if (slabEntry(A, B, rs, tmin, tn)) {                                                                               \
+                if (REF < 0) {                  /* leaf: its triangles now */                                                  \
+                    const int count = (int)(((uint32_t)REF >> 24) & 0x7fu), first = REF & 0x00ffffff;                          \
+                    for (int j = 0; j < count; j++) {                                                                          \
+                        const float *T = tris + (size_t)(first + j) * 16;                                                      \
+                        const vec3 v0 = V3(T[0], T[1], T[2]), e1 = V3(T[3], T[4], T[5]), e2 = V3(T[6], T[7], T[8]);            \
+                        float b0, b1;                                                                                          \
+                        if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {                                                           \
+                            const vec3 p1 = V3(T[9], T[10], T[11]), p2 = V3(T[12], T[13], T[14]);                              \
+                            const float w = 1 - b0 - b1;                                                                       \
+                            const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));                               \
+                            const float t = length(sub(o, p));                                                                 \
+                            int f;                                                                                             \
+                            __builtin_memcpy(&f, &T[15], 4);                                                                   \
+                            if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }               \
+                        }                                                                                                      \
+                    }                                                                                                          \
+                } else { TK = tn; CK = REF; }                                                                                  \
+            }                                                                                                                  \
+        }
+        // (leaf entries first would prune a little more; the builder puts a node's leaves in its first slots instead)
+        PT_WIDE_ENTRY(0, r0, t0, c0)
+        PT_WIDE_ENTRY(1, r1, t1, c1)
+        PT_WIDE_ENTRY(2, r2, t2, c2)
+        PT_WIDE_ENTRY(3, r3, t3, c3)
+#undef PT_WIDE_ENTRY
+        // inner entries that were hit when they were tested: drop those a later leaf of this node has made irrelevant, then sort by
+        // entry distance with a five-exchange network on (distance, child) pairs in registers (static indices only)
+        if (c0 >= 0 && t0 > tmin * 1.0001f) c0 = -1;
+        if (c1 >= 0 && t1 > tmin * 1.0001f) c1 = -1;
+        if (c2 >= 0 && t2 > tmin * 1.0001f) c2 = -1;
+        if (c3 >= 0 && t3 > tmin * 1.0001f) c3 = -1;
+#define PT_CX(ta, ca, tb, cb) do { const bool sw_ = (ca < 0) || (cb >= 0 && tb < ta); const float tt_ = sw_ ? tb : ta; const int cc_ = sw_ ? cb : ca; \
+                                   tb = sw_ ? ta : tb; cb = sw_ ? ca : cb; ta = tt_; ca = cc_; } while (0)
+        PT_CX(t0, c0, t1, c1); PT_CX(t2, c2, t3, c3); PT_CX(t0, c0, t2, c2); PT_CX(t1, c1, t3, c3); PT_CX(t1, c1, t2, c2);
+#undef PT_CX
+        // nearest in hand, the others onto the stack farthest first
+        if (c3 >= 0) { stack[sp * stride] = c3; sp++; }
+        if (c2 >= 0) { stack[sp * stride] = c2; sp++; }
+        if (c1 >= 0) { stack[sp * stride] = c1; sp++; }
+        int next = c0;
+        if (next < 0) {
+            if (sp == 0) return tmin;
+            next = stack[--sp * stride];
+        }
+        n = next;
+    }
+}
+
 // meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space
 // distance, as the reference does.  (intersectionPoint, which the reference also fills, has no reader.)
 // LDSF: the caller knows that the triangle tables are staged in LDS (sc.tri_lds && sc.ntri_lds): every table read is then a
 // ds_read from a pointer the compiler can see is LDS, instead of a run-time choice per word
 template <bool LDSF = false>
 PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, int bvhRoot = -1, int j0 = 0, int j1 = 0x7fffffff,
-                          int32_t *stack = nullptr, int stride = 0) {
+                          int32_t *stack = nullptr, int stride = 0, int wideRoot = -1) {
     Ray q;
     q.o = multiplyMV(geom.inv, r.o, 1.0f);
     q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
@@ -615,7 +712,8 @@ PT_DEV float meshTestCore(const DScene &sc, const DGeom &geom, Ray r, Cand &c, i
     if (bvhRoot >= 0) {
         // same per-triangle arithmetic, same winner (nearest distance, lowest face index): see pt_bvh.h
         float b0, b1;
-        if (stack) tmin = bvhNearestOrdered(sc.bvh_nodes, sc.bvh_tris, bvhRoot, q.o, q.d, nearest, b0, b1, stack, stride);
+        if (stack && wideRoot >= 0) tmin = bvhNearestWide(sc.bvh_nodes, sc.bvh_wide, sc.bvh_tris, bvhRoot, wideRoot, q.o, q.d, nearest, b0, b1, stack, stride);
+        else if (stack) tmin = bvhNearestOrdered(sc.bvh_nodes, sc.bvh_tris, bvhRoot, q.o, q.d, nearest, b0, b1, stack, stride);
         else tmin = bvhNearest(sc.bvh_nodes, sc.bvh_tris, bvhRoot, q.o, q.d, nearest, b0, b1);
         if (nearest >= 0) {
             const int f = geom.faceStart + nearest;
@@ -968,8 +1066,11 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
             t = meshTestCore<LDSF>(sc, geom, ray, c, -1, chunk * MESH_CHUNK, chunk * MESH_CHUNK + MESH_CHUNK);
     } else {
         // (a stack, when the caller has one and the tree fits it, buys the front-to-back search)
-        const bool ordered = stack && sc.bvh_depth && sc.bvh_depth[g] < sc.bvh_stack;
-        t = meshTestCore<LDSF>(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1, 0, 0x7fffffff, ordered ? stack : nullptr, stride);
+        // (four-wide nodes where the tree has them and the stack is long enough for their walk)
+        const bool wideok = stack && sc.bvh_wroot && sc.bvh_wroot[g] >= 0 && sc.bvh_wneed[g] <= sc.bvh_stack;
+        const bool ordered = wideok || (stack && sc.bvh_depth && sc.bvh_depth[g] < sc.bvh_stack);
+        t = meshTestCore<LDSF>(sc, geom, ray, c, sc.bvh_root ? sc.bvh_root[g] : -1, 0, 0x7fffffff, ordered ? stack : nullptr, stride,
+                               wideok ? sc.bvh_wroot[g] : -1);
     }
     if (!(t > 0.0f && t < 3.402823466e+38f)) return KEY_NONE;
     return packKey(t, g, (uint32_t)c.face);

@@ -1363,6 +1363,7 @@ struct ptx_tracer {
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr, *d_bvh_depth = nullptr;   // pt_bvh.h (NULL: no mesh has one)
+    BvhWide4 *d_bvh_wide = nullptr; int32_t *d_bvh_wroot = nullptr, *d_bvh_wneed = nullptr;                                  // four-wide nodes of the same trees (k_mesh)
     int ntri_lds = 0, bvh_nodes = 0, bvh_meshes = 0, bvh_stack = BVH_STACK;
     int mesh_chunks = 1;                                 // see DScene::mesh_chunks
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
@@ -1420,7 +1421,7 @@ struct ptx_tracer {
     DScene scene() const {
         DScene s; s.geoms = d_geoms; s.mats = d_mats; s.faces = d_faces; s.tri9 = d_tri9; s.texels = d_texels; s.ngeoms = ngeoms; s.nmats = nmats;
         s.gtab = d_gtab; s.aabb = d_aabb; s.cull = 0; s.cube_bits = cube_bits; s.sphere_bits = sphere_bits; s.mesh_bits = mesh_bits;
-        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.bvh_stack = 0; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
+        s.bvh_nodes = d_bvh_nodes; s.bvh_tris = d_bvh_tris; s.bvh_root = d_bvh_root; s.bvh_depth = d_bvh_depth; s.bvh_wide = d_bvh_wide; s.bvh_wroot = d_bvh_wroot; s.bvh_wneed = d_bvh_wneed; s.bvh_stack = 0; s.ntri_lds = 0; s.mesh_chunks = mesh_chunks;
         s.fnorm = d_fnorm; s.cnorm = d_cnorm; s.bump_bits = bump_bits;
         s.tri_lds = 0; s.ntri = ntri;      // tri_lds is switched on only by launches that stage the table (k_bounce)
         s.ldsblob = nullptr;               // (set by enqueue_batch together with tri_lds / ntri_lds: the blob is laid out for those)
@@ -1494,7 +1495,7 @@ int free_tracer(ptx_tracer *t) {
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamSynchronize(t->lane_stream[l]);      // work traced ahead
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_ldsblob); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_bvh_wide); hipFree(t->d_bvh_wroot); hipFree(t->d_bvh_wneed); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_ldsblob); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_cache_chunk); hipFree(t->d_cache_super);
@@ -1921,15 +1922,24 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     {
         BvhBuild bb;
         std::vector<int32_t> roots((size_t)std::max(ngeoms, 1), -1), depths((size_t)std::max(ngeoms, 1), 0);
+        std::vector<int32_t> wroots((size_t)std::max(ngeoms, 1), -1), wneeds((size_t)std::max(ngeoms, 1), 0);
+        const bool use_wide = getenv("PTX_DEBUG_NO_WIDE_BVH") == nullptr;          // (A/B timing, tests of both walks)
         for (int i = 0; i < ngeoms; i++)
             if (hg[i].type == G_OBJ && hg[i].faceCount >= BVH_MIN_FACES && !opt.no_bvh) {
-                roots[i] = bvhBuild(hfaces.data(), htri9.data(), hg[i].faceStart, hg[i].faceCount, bb, &depths[i]);
+                roots[i] = bvhBuild(hfaces.data(), htri9.data(), hg[i].faceStart, hg[i].faceCount, bb, &depths[i], &wroots[i], &wneeds[i]);
+                if (!use_wide) wroots[i] = -1;
                 t->bvh_meshes++;
             }
         t->bvh_nodes = (int)(bb.nodes.size() / 2);
         {   // stack entries per lane for k_mesh: deepest tree + 1 (a tree of depth d needs d + 1), at least 8, at most BVH_STACK
             int deepest = 0;
-            for (int i = 0; i < ngeoms; i++) if (roots[i] >= 0 && depths[i] < BVH_STACK) deepest = std::max(deepest, depths[i]);
+            // (a tree walks its four-wide nodes when their walk fits BVH_STACK entries, else the binary tree front to back when
+            // that fits, else the skip links: the stack is as long as the longest walk that is taken)
+            for (int i = 0; i < ngeoms; i++) {
+                if (roots[i] < 0) continue;
+                if (wroots[i] >= 0 && wneeds[i] <= BVH_STACK) deepest = std::max(deepest, wneeds[i] - 1);
+                else if (depths[i] < BVH_STACK) deepest = std::max(deepest, depths[i]);
+            }
             t->bvh_stack = std::min(BVH_STACK, std::max(8, deepest + 1));
         }
         if (!t->bvh_meshes && !getenv("PTX_DEBUG_NO_CHUNKS"))          // spread the loops of small meshes over lanes (tileIntersect)
@@ -1944,6 +1954,14 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             HC(hipMemcpy(t->d_bvh_root, roots.data(), sizeof(int32_t) * roots.size(), hipMemcpyHostToDevice));
             HC(hipMalloc(&t->d_bvh_depth, sizeof(int32_t) * depths.size()));
             HC(hipMemcpy(t->d_bvh_depth, depths.data(), sizeof(int32_t) * depths.size(), hipMemcpyHostToDevice));
+            if (use_wide && !bb.wide.empty()) {
+                HC(hipMalloc(&t->d_bvh_wide, sizeof(BvhWide4) * bb.wide.size()));
+                HC(hipMemcpy(t->d_bvh_wide, bb.wide.data(), sizeof(BvhWide4) * bb.wide.size(), hipMemcpyHostToDevice));
+                HC(hipMalloc(&t->d_bvh_wroot, sizeof(int32_t) * wroots.size()));
+                HC(hipMemcpy(t->d_bvh_wroot, wroots.data(), sizeof(int32_t) * wroots.size(), hipMemcpyHostToDevice));
+                HC(hipMalloc(&t->d_bvh_wneed, sizeof(int32_t) * wneeds.size()));
+                HC(hipMemcpy(t->d_bvh_wneed, wneeds.data(), sizeof(int32_t) * wneeds.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     // materials and geom tables go to LDS; the triangle tables join them when that leaves room for at least 2 workgroups
@@ -2613,8 +2631,10 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
     }
     BvhBuild bb;
     int depth = 0;
-    const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb, &depth);
-    long long visited = 0, visited_ordered = 0, mismatches = 0;
+    int wroot = -1, wneed = 0;
+    const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb, &depth, &wroot, &wneed);
+    std::vector<int32_t> wstack((size_t)std::max(wneed, 1) + 1, 0x7fffffff);      // (+ a guard word: the walk must never reach it)
+    long long visited = 0, visited_ordered = 0, visited_wide = 0, mismatches = 0;
     for (int i = 0; i < nrays; i++) {
         const vec3 o = V3(rays6[i * 6 + 0], rays6[i * 6 + 1], rays6[i * 6 + 2]);
         const vec3 d = normalize(V3(rays6[i * 6 + 3], rays6[i * 6 + 4], rays6[i * 6 + 5]));
@@ -2630,11 +2650,19 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
             visited_ordered += vis2;
             if (f2 != f1 || memcmp(&t2, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&c0, &b0, 4) != 0 || memcmp(&c1, &b1, 4) != 0))) mismatches++;
         }
+        if (wroot >= 0) {                       // ... and so must the walk over the four-wide nodes
+            int f3, vis3 = 0;
+            float e0, e1;
+            const float t3 = bvhNearestWide(bb.nodes.data(), bb.wide.data(), bb.tris.data(), root, wroot, o, d, f3, e0, e1, wstack.data(), 1, &vis3);
+            visited_wide += vis3;
+            if (wstack[(size_t)std::max(wneed, 1)] != 0x7fffffff) mismatches += 1000000;      // the walk overran the stack bound the builder computed
+            if (f3 != f1 || memcmp(&t3, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&e0, &b0, 4) != 0 || memcmp(&e1, &b1, 4) != 0))) mismatches++;
+        }
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;
     }
     if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / 16); stats4[2] = visited; stats4[3] = mismatches; }
-    (void)visited_ordered;
+    (void)visited_ordered; (void)visited_wide;
     return PTX_OK;
 }
 

@@ -60,7 +60,7 @@ def assert_same(res):
     fl, tl, fb, tb, st = res
     assert beq(fl, fb), "faces differ at %s" % np.nonzero(fl != fb)[0][:8]
     assert beq(tl, tb)
-    assert st[3] == 0, "front-to-back traversal disagrees with the skip-link traversal on %d rays" % st[3]
+    assert st[3] == 0, "the front-to-back walk or the walk over the four-wide quantised nodes disagrees with the skip-link walk on %d rays (>= 1e6: the wide walk overran its stack bound)" % st[3]
     return fl, st
 
 

@@ -393,7 +393,7 @@ def test_full_size_c1_c2_c3_against_the_reference(gpu_product, tag, scene, res, 
         assert beq(T.read_image(), ten)
 
 
-def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product):
+def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product, monkeypatch):
     """BASELINE config 5 at full size (3840x2160, depth 8, AA + DoF, textured 20448-triangle stand-in): minutes for
     the CPU oracle (it runs at 1920x1080 in test_c5_with_the_20k_triangle_mesh_against_oracle, and at full size with the
     320-triangle mesh in test_full_size_c5_against_oracle), so here the size-independent property is checked -- the fast path (BVH, mesh search as a kernel of
@@ -409,6 +409,11 @@ def test_full_size_c5_tree_and_split_equal_the_plain_loop(gpu_product):
         T.render(1, 2)
         assert beq(T.read_image(), fast) and T.stats()["rays_total"] == rays
     assert np.isfinite(fast).all() and (fast >= 0).all() and fast.max() > 0
+    # k_mesh walks the four-wide quantised nodes by default (round 3); the binary front-to-back walk gives the same frame
+    monkeypatch.setenv("PTX_DEBUG_NO_WIDE_BVH", "1")
+    with gpu_product.Tracer(s, depth_of_field=1) as T:
+        T.render(1, 2)
+        assert beq(T.read_image(), fast) and T.stats()["rays_total"] == rays
 
 
 def test_tuning_knobs_do_not_change_results(gpu_product, O, monkeypatch):
