@@ -37,8 +37,9 @@
 // The traversal (bvhNearest) lives in pt_device.h next to the triangle test; this header is the host-side builder.
 // Layout ("threaded" preorder, no stack): node = 2 x 16 bytes {lo.xyz, skip}{hi.xyz, leaf}.  skip = the next node
 // when this one is missed or is a leaf (-1 = done); an inner node that is hit continues at n + 1.  leaf = count << 28
-// | first (count 0 = inner, the low bits then name its right child).  Leaf triangles are stored in leaf order, 16 floats each: v0, e1, e2 (as tri9), the
-// vertices p1, p2 the reference interpolates the hit point from, and the face index inside the geom.
+// | first (count 0 = inner, the low bits then name its right child).  Leaf triangles are stored in leaf order, BVH_TRI = 12 words each: the
+// three vertices as loaded (the walk forms e1 = p1 - v0, e2 = p2 - v0 itself: the same subtractions as the upload-time table, and the
+// reference interpolates the hit point from v0, p1, p2), the face index inside the geom, two pads.
 #pragma once
 #include "pt_device.h"
 #include <algorithm>
@@ -51,7 +52,7 @@ namespace ptd {
 // ---- host-side builder: binned SAH, leaves of <= BVH_LEAF_MAX triangles ------------------------------------------
 struct BvhBuild {
     std::vector<BvhQuad> nodes;           // 2 per node, appended to whatever is already there
-    std::vector<float> tris;              // 16 per leaf triangle, appended likewise
+    std::vector<float> tris;              // BVH_TRI per leaf triangle, appended likewise
     std::vector<BvhWide4> wide;           // 4 per four-wide quantised node = 16 words (bvhNearestWide), appended likewise
 };
 
@@ -166,7 +167,7 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
     double mdiag = 0.0;
     for (int k = 0; k < 3; k++) mdiag += (tree[0].hi[k] - tree[0].lo[k]) * (tree[0].hi[k] - tree[0].lo[k]);
     mdiag = std::sqrt(mdiag);
-    const int base = (int)(out.nodes.size() / 2), tbase = (int)(out.tris.size() / 16);
+    const int base = (int)(out.nodes.size() / 2), tbase = (int)(out.tris.size() / BVH_TRI);
     out.nodes.resize(out.nodes.size() + 2 * tree.size());
     // preorder == creation order of buildRec (node, left subtree, right subtree), so node i sits at base + i
     std::vector<int> skip(tree.size(), -1);
@@ -267,15 +268,16 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
         if (wroot_out) *wroot_out = wroot;
         if (wneed_out) *wneed_out = (nw ? need[0] : 0) + 1;
     }
-    out.tris.resize(out.tris.size() + (size_t)faceCount * 16);
+    out.tris.resize(out.tris.size() + (size_t)faceCount * BVH_TRI);
     for (int i = 0; i < faceCount; i++) {
         const int j = pr[i].face;
-        const float *f = faces15 + (size_t)(faceStart + j) * 15, *t9 = tri9 + (size_t)(faceStart + j) * 9;
-        float *o = &out.tris[(size_t)(tbase + i) * 16];
-        for (int k = 0; k < 9; k++) o[k] = t9[k];
-        for (int k = 0; k < 3; k++) { o[9 + k] = f[5 + k]; o[12 + k] = f[10 + k]; }
-        memcpy(&o[15], &j, 4);
+        const float *f = faces15 + (size_t)(faceStart + j) * 15;
+        float *o = &out.tris[(size_t)(tbase + i) * BVH_TRI];
+        for (int k = 0; k < 3; k++) { o[k] = f[k]; o[3 + k] = f[5 + k]; o[6 + k] = f[10 + k]; }
+        memcpy(&o[9], &j, 4);
+        o[10] = o[11] = 0.f;
     }
+    (void)tri9;
     return base;
 }
 

@@ -213,6 +213,7 @@ constexpr int MESH_CHUNK = PT_MESH_CHUNK;
 #endif
 constexpr int BVH_LEAF_MAX = PT_BVH_LEAF;
 constexpr int BVH_MIN_FACES = 24;        // meshes smaller than this keep the plain loop
+constexpr int BVH_TRI = 12;              // words per leaf triangle: v0, p1, p2 (the vertices as loaded), face index, two pads -- three 16-byte loads
 constexpr int BVH_STACK = 32;            // entries per lane of k_mesh's traversal stack (trees deeper than 31 use the skip links)
 struct DScene {
     const DGeom *__restrict__ geoms;
@@ -234,7 +235,7 @@ struct DScene {
     const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box (min xyz, pad, max xyz, pad), or NULL
     uint32_t cube_bits, sphere_bits, mesh_bits;   // bit i: geom i is a cube / sphere / mesh (unknown types are in none)
     const BvhQuad *__restrict__ bvh_nodes;          // threaded BVH of the larger meshes (pt_bvh.h), or NULL
-    const float *__restrict__ bvh_tris;             // 16 floats per leaf triangle
+    const float *__restrict__ bvh_tris;             // BVH_TRI words per leaf triangle
     const int32_t *__restrict__ bvh_root;           // per geom: root node, -1 = plain loop over its faces
     const int32_t *__restrict__ bvh_depth;          // per geom: depth of its tree (root = 0)
     int32_t bvh_stack;                              // entries per lane of the traversal stack the launch provides (k_mesh): trees of
@@ -520,16 +521,17 @@ PT_HD float bvhNearest(const BvhQuad *__restrict__ nodes, const float *__restric
         const int count = (int)((uint32_t)B.w >> 28), first = B.w & 0x0fffffff;
         if (count == 0) { n = n + 1; continue; }
         for (int k = 0; k < count; k++) {
-            const float *T = tris + (size_t)(first + k) * 16;
-            const vec3 v0 = V3(T[0], T[1], T[2]), e1 = V3(T[3], T[4], T[5]), e2 = V3(T[6], T[7], T[8]);
+            const float *T = tris + (size_t)(first + k) * BVH_TRI;
+            // (e1 = p1 - v0, e2 = p2 - v0: the subtractions the upload-time table holds, done here -- same IEEE results, one load less)
+            const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);
+            const vec3 e1 = sub(p1, v0), e2 = sub(p2, v0);
             float b0, b1;
             if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {
-                const vec3 p1 = V3(T[9], T[10], T[11]), p2 = V3(T[12], T[13], T[14]);
                 const float w = 1 - b0 - b1;
                 const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
                 const float t = length(sub(o, p));
                 int f;
-                __builtin_memcpy(&f, &T[15], 4);
+                __builtin_memcpy(&f, &T[9], 4);
                 if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }
             }
         }
@@ -565,16 +567,16 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
         int next = -1;
         if (count) {
             for (int k = 0; k < count; k++) {
-                const float *T = tris + (size_t)(first + k) * 16;
-                const vec3 v0 = V3(T[0], T[1], T[2]), e1 = V3(T[3], T[4], T[5]), e2 = V3(T[6], T[7], T[8]);
+                const float *T = tris + (size_t)(first + k) * BVH_TRI;
+                const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);
+                const vec3 e1 = sub(p1, v0), e2 = sub(p2, v0);
                 float b0, b1;
                 if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {
-                    const vec3 p1 = V3(T[9], T[10], T[11]), p2 = V3(T[12], T[13], T[14]);
                     const float w = 1 - b0 - b1;
                     const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
                     const float t = length(sub(o, p));
                     int f;
-                    __builtin_memcpy(&f, &T[15], 4);
+                    __builtin_memcpy(&f, &T[9], 4);
                     if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }
                 }
             }
@@ -652,16 +654,16 @@ PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__
                 if (REF < 0) {                  /* leaf: its triangles now */                                                  \
                     const int count = (int)(((uint32_t)REF >> 24) & 0x7fu), first = REF & 0x00ffffff;                          \
                     for (int j = 0; j < count; j++) {                                                                          \
-                        const float *T = tris + (size_t)(first + j) * 16;                                                      \
-                        const vec3 v0 = V3(T[0], T[1], T[2]), e1 = V3(T[3], T[4], T[5]), e2 = V3(T[6], T[7], T[8]);            \
+                        const float *T = tris + (size_t)(first + j) * BVH_TRI;                                                 \
+                        const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);            \
+                        const vec3 e1 = sub(p1, v0), e2 = sub(p2, v0);                                                         \
                         float b0, b1;                                                                                          \
                         if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {                                                           \
-                            const vec3 p1 = V3(T[9], T[10], T[11]), p2 = V3(T[12], T[13], T[14]);                              \
                             const float w = 1 - b0 - b1;                                                                       \
                             const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));                               \
                             const float t = length(sub(o, p));                                                                 \
                             int f;                                                                                             \
-                            __builtin_memcpy(&f, &T[15], 4);                                                                   \
+                            __builtin_memcpy(&f, &T[9], 4);                                                                   \
                             if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }               \
                         }                                                                                                      \
                     }                                                                                                          \

@@ -2661,7 +2661,7 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;
     }
-    if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / 16); stats4[2] = visited; stats4[3] = mismatches; }
+    if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / BVH_TRI); stats4[2] = visited; stats4[3] = mismatches; }
     (void)visited_ordered; (void)visited_wide;
     return PTX_OK;
 }
