@@ -1033,6 +1033,21 @@ def test_edge_many_materials(gpu_product, O, tmp_path):
     _vs_oracle(gpu_product, O, s, iters=4)
     _vs_oracle(gpu_product, O, s, iters=4, batch=1)
     _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1, antialiasing=0)
+    # the same scene on a frame large enough for full grids: 70 bins x 32 groups of 64 workgroups = 2240 entries in the table the run
+    # search scans first (several 512-entry trips), 1792 workgroups per launch when one iteration is traced at a time, mostly
+    # empty runs (windows that move on many times); the stream after two bounces and the frames, against the oracle
+    s.set_resolution(960, 540)
+    s.apply_runcuda_camera()
+    O.set_threads(16)
+    try:
+        _vs_oracle(gpu_product, O, s, iters=3, batch=1, lanes=1)
+        _vs_oracle(gpu_product, O, s, iters=3)
+        d = s.dump()
+        O.set_libm(1); O.create(d, d["textures"]); O.set_options(aa=1, dof=0, sort=1, cache=1); O.pt_init()
+        with gpu_product.Tracer(s) as T:
+            check_sorted_streams(T, O, d, 6)
+    finally:
+        O.set_threads(1)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
