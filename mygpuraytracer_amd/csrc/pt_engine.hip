@@ -622,7 +622,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             const int A = tile0 * TILE;
             int pre_s = 0, pre_a = 0;
             // (rows of the group table are nsuper wide, entries past a bin's last group are zero: scanned as one flat array)
-            const int bs = scanFind8(in_super + (size_t)nb * p.nsuper, in_super, nb * p.nsuper, A, pre_s, pre_a, lane);      // A < n_in: there is one
+            int bs = scanFind8(in_super + (size_t)nb * p.nsuper, in_super, nb * p.nsuper, A, pre_s, pre_a, lane);      // A < n_in: there is one
+            bs = bs < 0 ? 0 : bs;      // (cannot happen while the tables are what a k_bounce leaves; no address may depend on that)
             const int b = bs / p.nsuper, sg = bs - b * p.nsuper;
             const int rs = b * p.in_gx + sg * 64;                     // first run of the group; its 64 runs hold position A
             int cs[2], ca[2], cb[2];
@@ -669,7 +670,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 int k = 0;
 #pragma unroll
                 for (int st = WIN / 2; st; st >>= 1) k += win[k + st] <= jp ? st : 0;      // last run that starts at or before jp
-                li4 = (uint32_t)(win[2 * (WIN + 1) + k] + (jp - win[k])) << 2;
+                // (the clamp cannot bite while the tables are consistent: it is there so that no gather address depends on that)
+                li4 = (uint32_t)min(win[2 * (WIN + 1) + k] + (jp - win[k]), p.maxTiles * TILE - 1) << 2;
                 idx_base = win[WIN + 1 + k];
                 done = true;
             }
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA in = soa_fresh(in_k);
         // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
         // slot of that bounce's stage and the path's rank inside its run
-        const uint32_t j4 = (uint32_t)ld_u(in.lsrc(), li4) << 2;
+        const uint32_t j4 = min((uint32_t)ld_u(in.lsrc(), li4), (uint32_t)(p.maxTiles * TILE - 1)) << 2;
         r.idx = idx_base + ld_u(in.lidx(), li4);
 #pragma unroll
         for (int k = 0; k < 12; k++) r.f[k] = ld_u(in.field(k), j4);
