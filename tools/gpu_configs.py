@@ -26,4 +26,4 @@ for tag, scene, res, depth, opt, iters in CASES:
             rays = (T.stats()["rays_total"] - r0) / iters
         print(json.dumps(dict(config=tag, scene=scene, res=res, depth=depth, opt=opt, ms_per_iter=round(1e3 * dt / iters, 4),
                               mrays_per_iter=round(rays / 1e6, 3), grays_s=round(rays / (dt / iters) / 1e9, 3),
-                              loop_roofline_frac=round(436 * rays / (dt / iters) / 8e12, 3))), flush=True)
+                              contract_436B_loop_ratio=round(436 * rays / (dt / iters) / 8e12, 3))), flush=True)
