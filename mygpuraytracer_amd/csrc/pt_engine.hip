@@ -443,6 +443,44 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     TI_STAMP(7);
 }
 
+// What pass 1 of the split bounce (and k_finish, for the rays pass 1 parked) tells pass 2 about ray i: one word, lsrc[i] of the stage
+// until the tail overwrites it.  CAND = parked with mesh candidates in slot (bits 16-23) of its tile, k_finish will replace the
+// word; otherwise the ray is finished -- alive / stored flags, its bin (bits 0-15) and, if stored, the slot its record lies in.
+constexpr int32_t K1_CAND = (int32_t)0x80000000u, K1_ALIVE = 0x40000000, K1_PEND = 0x20000000;
+
+// The terminal cases of shadeFakeMaterial(b) for a path whose nearest hit is known (src/pathtrace.cu:380-390, :400): light =>
+// radiance, miss or last bounce => black, otherwise the path is stored for the next bounce (pending); also the path's material bin.
+template <bool FIRST>
+__device__ __forceinline__ void classifyPath(const BounceParams &p, int iter, float *part, bool batched, const Hit &hit, vec3 color, int pix,
+                                             int &bin, bool &pending) {
+    bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;           // material descending; a miss carries id 0
+    if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)slot_to_pixel(p.tm, pix) * 3);
+    bool lit = false;
+    if (hit.t > 0.0f) {
+        const DMaterial m = getMaterial(p.sc, hit.mat);
+        if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
+            lit = true;
+            vec3 c = mul(color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
+            deposit(p.tm, p.image, part, batched, pix, c, p.apps);
+            if (FIRST && p.emit_count) {
+                const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
+                int k = atomicAdd(p.emit_count, 1);
+                p.emit_pix[k] = pix;
+                p.emit_rgb[k * 3 + 0] = cd.x; p.emit_rgb[k * 3 + 1] = cd.y; p.emit_rgb[k * 3 + 2] = cd.z;
+            }
+        } else if (p.traceDepth - p.bounce != 1) {         // :387-390 (last bounce => black)
+            pending = true;
+        }
+    }
+    // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
+    // in batched mode the path's slot of the per-iteration buffer must still be written
+    if (batched && !pending && !lit) {
+        float z = 0.f;
+        asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
+        st_rgb(part, (uint32_t)pix * 12u, z, z, z);
+    }
+}
+
 // inclusive prefix sum over the lanes of a wave
 __device__ __forceinline__ int waveInclusiveScan(int v, int lane) {
 #pragma unroll
@@ -571,7 +609,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     // [nbins] tile counts [nbins+1] tile offsets [17][TILE] records being sorted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = p.nbins;
-    const int triWords = p.sc.tri_lds ? sceneLdsWords(p.sc) : 0;
+    const int triWords = (MODE != 2 && p.sc.tri_lds) ? sceneLdsWords(p.sc) : 0;      // (pass 2 of the split bounce only ranks: no scene tables)
     int32_t *lds = pt_lds + triWords;
     int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
@@ -651,7 +689,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             }
         } else if (p.sc.tri_lds) stageSceneToLds(p.sc, tid - 64, TILE - 64);
         __syncthreads();
-    } else if (tile0 < tile1 && p.sc.tri_lds) {      // (a workgroup without tiles shades nothing and needs no tables)
+    } else if (MODE != 2 && tile0 < tile1 && p.sc.tri_lds) {      // (a workgroup without tiles shades nothing and needs no tables; nor does pass 2)
         stageSceneToLds(p.sc, tid, TILE);
         __syncthreads();
     }
@@ -695,6 +733,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
         r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
     };
+    auto classifyRay = [&](const Hit &hit, const PathState &ps, int pix, int &bin, bool &pending) {
+        classifyPath<FIRST>(p, iter, part, batched, hit, ps.color, pix, bin, pending);
+    };
+    int32_t *ccnt = qcnt + 2;                                   // MODE 1: candidates of the tile so far (LDS)
     for (int tile = tile0; tile < tile1; tile++) {
 #ifdef PT_STAMPS
         st_t0 = __builtin_amdgcn_s_memtime();
@@ -724,15 +766,18 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
             continue;
         }
-        if (MODE == 2) {                 // parked by MODE 1 in this tile's stage slots
+        int bin = -1;
+        bool pending = false, pass1_partial = false;
+        int32_t k1 = 0;
+        int myslot = 0;                  // split bounce: the slot (inside the tile) of this ray's parked state / stored record
+        if (MODE == 1 && tid == 0) *ccnt = 0;           // (first touched after tileIntersect's barriers)
+        if (MODE == 2) {                 // pass 1 left one word per ray; only the rays with mesh candidates were parked
             alive = false;
             if (i < n_in) {
-                pix = stage.pix()[i];
-                alive = pix >= 0;
-                ps.o = V3(stage.px()[i], stage.py()[i], stage.pz()[i]);
-                ps.d = V3(stage.dx()[i], stage.dy()[i], stage.dz()[i]);
-                ps.color = V3(stage.cr()[i], stage.cg()[i], stage.cb()[i]);
-                key = (p.keys + p.seg_keys * seg)[i];
+                // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
+                k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
+                myslot = (k1 >> 16) & 0xff;
+                alive = (k1 & K1_ALIVE) != 0; pending = (k1 & K1_PEND) != 0; bin = k1 & 0xffff;
             }
         } else if (alive) {
             if (FIRST) {
@@ -769,8 +814,6 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         STAMP(0);        // load + shade (or ray generation)
         // computeIntersections(b) + the terminal cases of shadeFakeMaterial(b)
-        int bin = -1;
-        bool pending = false;
         Hit hit;
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
         {
@@ -792,17 +835,32 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                                          p.uses_uv != 0, hit);
                     goto classify;
                 }
-                // park the ray and queue its mesh candidates: per mesh present in the wave one atomic for the base
-                if (i < n_in) {
-                    stage.px()[i] = ray.o.x; stage.py()[i] = ray.o.y; stage.pz()[i] = ray.o.z;
-                    stage.dx()[i] = ray.d.x; stage.dy()[i] = ray.d.y; stage.dz()[i] = ray.d.z;
-                    stage.cr()[i] = ps.color.x; stage.cg()[i] = ps.color.y; stage.cb()[i] = ps.color.z;
-                    stage.pix()[i] = alive ? pix : -1;
-                    (p.keys + p.seg_keys * seg)[i] = key;
-                }
-                // queue entries go through an LDS buffer (the upper part of `rec`, free in this mode) and reach the global
-                // queue in blocks: one global atomic per ~30 tiles instead of one per wave (a single hot counter)
+                // A ray WITH mesh candidates is parked -- origin, direction, colour, pixel, best key so far, in a slot of its own
+                // counted down from the top of the tile -- and its candidates are queued with that slot.  A ray without -- 93 % of
+                // them past the first bounce -- is finished right here like the unsplit kernel would: nearest hit, terminal cases,
+                // ranked and sorted by bin among its like, record written to the bottom of the tile; pass 2 gets ONE word about it
+                // (round 3; rounds 1-2 parked every ray: 48 B out and 48 B back in for each, which is what bounded the two passes).
+                // What pass 2 still does for all is the ranking that defines the order: it needs every ray's bin, and the
+                // candidates' are not known before k_mesh.
+                pass1_partial = true;
                 {
+                    const bool is_cand = mesh_cand != 0u;                        // (implies alive)
+                    const unsigned long long cb = __ballot(is_cand);
+                    int cbase = 0;
+                    if (lane == 0 && cb) cbase = atomicAdd(ccnt, __popcll(cb));
+                    myslot = TILE - 1 - (__builtin_amdgcn_readfirstlane(cbase) + wavePrefix(cb, lane));
+                    const int sa = tile * TILE + myslot;
+                    if (is_cand) {
+                        stage.px()[sa] = ray.o.x; stage.py()[sa] = ray.o.y; stage.pz()[sa] = ray.o.z;
+                        stage.dx()[sa] = ray.d.x; stage.dy()[sa] = ray.d.y; stage.dz()[sa] = ray.d.z;
+                        stage.cr()[sa] = ps.color.x; stage.cg()[sa] = ps.color.y; stage.cb()[sa] = ps.color.z;
+                        stage.pix()[sa] = pix;
+                        stage.mg()[sa] = i;                                      // whose ray this is: k_finish writes the verdict to lsrc[i]
+                        (p.keys + p.seg_keys * seg)[sa] = key;
+                        k1 = K1_CAND | (myslot << 16);
+                    }
+                    // queue entries go through an LDS buffer (behind the record buffer) and reach the global queue in blocks: one
+                    // global atomic per ~30 tiles instead of one per wave (a single hot counter)
                     const int mine = (int)__popc(mesh_cand);                     // 0 .. SPLIT_MAX_MESHES
                     const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2);
                     const int wtot = __popcll(b0) + 2 * __popcll(b1);
@@ -813,15 +871,14 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                     for (int j = 0; j < mine; j++) {
                         const int g = __ffs((int)m) - 1;
                         m &= m - 1;
-                        qbuf[base + j] = (uint32_t)i | ((uint32_t)g << 26);
+                        qbuf[base + j] = (uint32_t)sa | ((uint32_t)g << 26) | (j == 0 ? 0x80000000u : 0u);      // bit 31: the ray's first entry
                     }
+                    if (is_cand) alive = false;                                  // not part of pass 1's ranking and records
                 }
-                __syncthreads();
-                if (*qcnt > QCAP - TILE * SPLIT_MAX_MESHES) flushQueue(p, seg, qbuf, qcnt, qbase, tid);
-                continue;                // (the barrier above also frees scratch and histogram for the next tile)
-            } else if (MODE == 2) {
                 if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
                                      p.uses_uv != 0, hit);
+                goto classify;
+            } else if (MODE == 2) {
                 __syncthreads();                                  // histogram zeroed
             } else if (p.sc.cull) {
                 // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 72 registers.  The thread's own state
@@ -852,34 +909,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         STAMP(1);        // intersect
     classify:
-        if (alive) {
-            bin = p.sort ? (p.sc.nmats - 1 - hit.mat) : 0;       // material descending; a miss carries id 0
-            if (FIRST && p.albedo && iter == 1) write_albedo(p.sc, hit, p.albedo + (size_t)slot_to_pixel(p.tm, pix) * 3);
-            bool lit = false;
-            if (hit.t > 0.0f) {
-                const DMaterial m = getMaterial(p.sc, hit.mat);
-                if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
-                    lit = true;
-                    vec3 c = mul(ps.color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-                    deposit(p.tm, p.image, part, batched, pix, c, p.apps);
-                    if (FIRST && p.emit_count) {
-                        const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
-                        int k = atomicAdd(p.emit_count, 1);
-                        p.emit_pix[k] = pix;
-                        p.emit_rgb[k * 3 + 0] = cd.x; p.emit_rgb[k * 3 + 1] = cd.y; p.emit_rgb[k * 3 + 2] = cd.z;
-                    }
-                } else if (p.traceDepth - p.bounce != 1) {         // :387-390 (last bounce => black)
-                    pending = true;
-                }
-            }
-            // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
-            // in batched mode the path's slot of the per-iteration buffer must still be written
-            if (batched && !pending && !lit) {
-                float z = 0.f;
-                asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
-                st_rgb(part, (uint32_t)pix * 12u, z, z, z);
-            }
-        }
+        if (MODE != 2 && alive) classifyRay(hit, ps, pix, bin, pending);
         STAMP(2);        // classify + deposit
         // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
         // index) and among the stored ones (-> storage position)
@@ -956,8 +986,21 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
         }
         STAMP(3);        // ranking + counts
+        if (MODE == 2) {                 // the records lie in their slots already (pass 1, or above): only the keys are left,
+            int32_t *keybuf = rec;       // one per SLOT (through LDS: a path's slot is not its thread), -1 where no record lies
+            keybuf[tid] = -1;
+            __syncthreads();
+            if (pending) keybuf[myslot] = stage_key(bin, r_all, r_scat);
+            __syncthreads();
+            st_u(soa_fresh(stage_k).idx(), (uint32_t)i << 2, keybuf[tid]);
+            continue;                    // (w_all / w_scat were last read before the barriers above: the next tile may zero them)
+        }
+        if (MODE == 1 && pass1_partial && i < n_in) {
+            if (alive) k1 = K1_ALIVE | bin | (pending ? K1_PEND | ((toff[bin] + r_scat) << 16) : 0);
+            st_u(soa_fresh(stage_k).lsrc(), (uint32_t)i << 2, k1);
+        }
         // Stored paths go to the stage sorted by bin inside the tile (through LDS), so that both this write and
-        // k_move's read are dense and coalesced and k_move's scattered write falls into per-bin runs.
+        // the tail's read are dense and coalesced and the next bounce's gather reads per-bin runs.
         if (pending) {
             const int slot = toff[bin] + r_scat;
             const vec3 sp = add(ps.o, scale(ps.d, hit.t));      // the point shadeFakeMaterial will shade (:392)
@@ -990,6 +1033,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         __syncthreads();
         STAMP(4);        // sort through LDS + stage write
+        if (MODE == 1 && *qcnt > QCAP - TILE * SPLIT_MAX_MESHES) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: read after a barrier)
     }
 #ifdef PT_STAMPS
     if (lane == 0 && p.stamps)
@@ -1077,12 +1121,53 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p)
     unsigned long long *keys = p.keys + p.seg_keys * seg;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint32_t item = items[k];
-        const int i = (int)(item & 0x3ffffffu), g = (int)(item >> 26);
+        const int i = (int)(item & 0x3ffffffu), g = (int)((item >> 26) & 31u);
         Ray r;
         r.o = V3(st.px()[i], st.py()[i], st.pz()[i]);
         r.d = V3(st.dx()[i], st.dy()[i], st.dz()[i]);
         const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r, -1, pt_lds + threadIdx.x, 256);
         if (key != KEY_NONE) atomicMin(&keys[i], key);
+    }
+}
+
+// Split mesh search, after k_mesh: one lane per PARKED ray (the queue entries that carry bit 31) finishes it -- nearest hit decoded
+// from the ray's final key, terminal cases, its record written into the slot it was parked in if it goes on -- and leaves the one
+// word pass 2 needs in lsrc[owner].  Dense lanes that all do the same thing: the dependent face / texel loads of a textured mesh
+// hit, which used to hold a whole tile at a barrier in pass 2, are hidden by the other waves here.  Scene tables from global memory.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
+    BounceParams p = p_in;
+    p.sc.tri_lds = 0; p.sc.ntri_lds = 0;                    // (no LDS tables in this kernel)
+    const int seg = blockIdx.y;
+    const int iter = p.iter + seg * p.iter_stride;
+    const int n = p.item_count[seg];
+    const PathSoA st = soa_offset(p.stage, p.seg_stage * seg);
+    const uint32_t *items = p.items + p.seg_items * seg;
+    const unsigned long long *keys = p.keys + p.seg_keys * seg;
+    float *part = p.part ? p.part + p.seg_part * seg : nullptr;
+    const bool batched = part != nullptr;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t item = items[k];
+        if (!(item >> 31)) continue;
+        const int sa = (int)(item & 0x3ffffffu);
+        const int owner = st.mg()[sa], pix = st.pix()[sa];
+        Ray ray;
+        ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
+        ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
+        const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
+        Hit hit;
+        decodeKey(p.sc, p.sc.gtab, keys[sa], ray, p.uses_uv != 0, hit);
+        int bin = 0;
+        bool pending = false;
+        classifyPath<FIRST>(p, iter, part, batched, hit, color, pix, bin, pending);
+        if (pending) {
+            const vec3 sp = add(ray.o, scale(ray.d, hit.t));          // the point shadeFakeMaterial will shade (:392)
+            st.px()[sa] = sp.x; st.py()[sa] = sp.y; st.pz()[sa] = sp.z;
+            st.nx()[sa] = hit.n.x; st.ny()[sa] = hit.n.y; st.nz()[sa] = hit.n.z;      // (direction, colour and pixel are in place)
+            if (p.uses_uv) { st.u()[sa] = hit.u; st.v()[sa] = hit.v; }
+            st.mg()[sa] = hit.mat | (hit.geom << 16);
+        }
+        st.lsrc()[owner] = K1_ALIVE | (pending ? K1_PEND : 0) | bin | ((sa & (TILE - 1)) << 16);
     }
 }
 
@@ -1700,7 +1785,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // SIMD, 32 entries x 256 lanes x 4 B = 32 KB per workgroup only 5): as many entries as the deepest tree needs
             mq.sc.bvh_stack = t->bvh_stack;
             KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
-            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
+            // (pass 2 neither intersects nor sorts through LDS: scene tables and the ranking head only)
+            if (first) KT(2, hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp));
+            else KT(2, hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp));
+            const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });

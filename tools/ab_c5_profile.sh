@@ -13,8 +13,8 @@ import csv,glob
 f=max(glob.glob("$R/gpurun_out/c5prof_$v/**/*kernel_stats.csv",recursive=True))
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    if "k_bounce" in n or "k_mesh" in n or "k_gather" in n:
-        short=n.split("(")[0].replace("void (anonymous namespace)::","")
+    if "k_bounce" in n or "k_mesh" in n or "k_gather" in n or "k_finish" in n:
+        short=n.replace("(anonymous namespace)::","").replace("void ","").split("(")[0]
         print("%-40s calls %5s avg_us %9.1f total_ms %8.2f" % (short[:40], r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
 P
 done
