@@ -737,6 +737,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         classifyPath<FIRST>(p, iter, part, batched, hit, ps.color, pix, bin, pending);
     };
     int32_t *ccnt = qcnt + 2;                                   // MODE 1: candidates of the tile so far (LDS)
+    int32_t k1_next = 0;                                        // MODE 2: the next tile's word, requested one tile ahead
+    if (MODE == 2 && !FIRST && tile0 < tile1 && tile0 * TILE + tid < n_in) k1_next = ld_u(soa_fresh(stage_k).lsrc(), (uint32_t)(tile0 * TILE + tid) << 2);
     for (int tile = tile0; tile < tile1; tile++) {
 #ifdef PT_STAMPS
         st_t0 = __builtin_amdgcn_s_memtime();
@@ -753,6 +755,13 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
+        int32_t k1 = 0;
+        if (MODE == 2 && !FIRST) {
+            // the word of the NEXT tile is requested before this tile's is used: the ranking pass is otherwise one exposed memory
+            // round trip per tile (pass 2 at 4K: 110 -> 85 us per launch; not on the first bounce, most of whose tiles pass 1 finished)
+            k1 = k1_next;
+            if (tile + 1 < tile1 && i + TILE < n_in) k1_next = ld_u(soa_fresh(stage_k).lsrc(), (uint32_t)(i + TILE) << 2);
+        }
         if (MODE == 2 && FIRST && p.tile_done && (p.tile_done + (size_t)p.maxTiles * seg)[tile]) {
             // pass 1 finished this tile (records and keys are in the stage): only its per-bin counts, which pass 1 left in
             // the prefix tables, are folded into this workgroup's running prefix
@@ -768,14 +777,13 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         int bin = -1;
         bool pending = false, pass1_partial = false;
-        int32_t k1 = 0;
         int myslot = 0;                  // split bounce: the slot (inside the tile) of this ray's parked state / stored record
         if (MODE == 1 && tid == 0) *ccnt = 0;           // (first touched after tileIntersect's barriers)
         if (MODE == 2) {                 // pass 1 left one word per ray; only the rays with mesh candidates were parked
             alive = false;
+            // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
             if (i < n_in) {
-                // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
-                k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
+                if (FIRST) k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
                 myslot = (k1 >> 16) & 0xff;
                 alive = (k1 & K1_ALIVE) != 0; pending = (k1 & K1_PEND) != 0; bin = k1 & 0xffff;
             }
