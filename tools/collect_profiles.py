@@ -9,7 +9,7 @@ in KiB and reads half of the bytes on gfx950, MI355X_MICROARCH.md "HBM").
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_bounce<false": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh"}
+NAMES = {"k_bounce<false": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh", "k_finish": "k_finish"}
 
 
 def main(tag, d_stats, d_fetch, d_write):

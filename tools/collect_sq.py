@@ -7,7 +7,7 @@ per launch plus a few derived figures (VALU lane utilisation, share of wave time
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"k_bounce<false": "k_bounce", "k_bounceILb0": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_bounceILb1": "k_bounce<first>",
-         "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh"}
+         "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh", "k_finish": "k_finish"}
 
 
 def main(tag):
