@@ -204,7 +204,8 @@ def test_cottage_mesh_from_vectors_on_device(gpu_product, O):
     LOADER returned it (tests/golden/loader_cottage.npz: geoms, 486 x 15 face floats, materials, camera) goes through ptx_create
     as plain arrays (Tracer.from_pod), with the BVH + split mesh search, fused, and with the reference's loop over all faces:
     meshIntersectionTest's golden rays, the sorted stream after every bounce, image and ray counts after 1 and 4 iterations --
-    against the oracle on the same arrays bit for bit, and against what the reference build rendered (render_cottage.npz)."""
+    against the oracle on the same arrays bit for bit, and against render_cottage.npz -- what oracle/_ref rendered: the reference's own
+    intersection / scatter functions inside the RESTATED bounce loop (make_golden.py PROVENANCE "restated"), not the reference's CUDA build."""
     from conftest import dump_from_golden
     g, r, k = golden("loader_cottage.npz"), golden("render_cottage.npz"), golden("isect_kat_cottage.npz")
     d = dump_from_golden(g, cam="cam_floats_runcuda")
@@ -318,7 +319,8 @@ RENDER_CASES = [
 
 @pytest.mark.parametrize("tag,scene,res,depth", RENDER_CASES)
 def test_images_match_reference_golden(gpu_product, O, tag, scene, res, depth):
-    """Accumulated radiance after 1, 2 and 16 iterations equals the reference's (golden, glibc libm) and the
+    """Accumulated radiance after 1, 2 and 16 iterations equals the golden frames (oracle/_ref: the reference's device functions inside the
+    RESTATED bounce loop, glibc libm -- frame-level parity is pinned against that restatement, not against the reference's CUDA build) and the
     oracle's bit for bit; so do the per-bounce ray counts and the 8-bit preview."""
     r = golden("render_%s.npz" % tag)
     aa, dof, sort, cache = map(int, r["options"])

@@ -99,7 +99,7 @@ RENDERS = ["c1_sphere", "c2_cornell_cache", "c3_glass", "c4_obj", "c5_dof", "nos
 
 def test_cottage_render(O):
     """The cottage scene from its vector fixture (loader_cottage.npz: the reference loader's geoms, faces, materials, camera at
-    96x54 depth 6): sorted streams of iteration 1, image and counts after 1 and 4 iterations as the reference build gave them."""
+    96x54 depth 6): sorted streams of iteration 1, image and counts after 1 and 4 iterations as oracle/_ref gave them (reference functions, restated loop)."""
     g, r = golden("loader_cottage.npz"), golden("render_cottage.npz")
     O.create(dump_from_golden(g, cam="cam_floats"))
     O.apply_runcuda_camera()
@@ -194,7 +194,7 @@ def test_threads_do_not_change_the_oracle(O, tag):
 
 def test_c1_plumbing_cpu_stream_compaction(O):
     """BASELINE config 1: sphere.txt 256x256 depth 4, 1 spp on the CPU path whose dead-ray compaction is the
-    StreamCompaction::CPU scan+scatter (oracle partition_paths); counts and radiance as the reference gives."""
+    StreamCompaction::CPU scan+scatter (oracle partition_paths); counts and radiance as oracle/_ref gives (reference functions, restated loop)."""
     g = golden("loader_sphere.npz")
     d = dump_from_golden(g, cam="cam_floats")
     cf = d["cam_floats"]
