@@ -283,8 +283,8 @@ def main():
                     "xGMI links into rank 0, no adds; SURVEY 8(e)); 'reduce' = reduce(SUM) of the full accumulation buffers, in which "
                     "foreign rows are zero -- the same frame bit for bit, N times the bytes")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8],
-                    help="launch sets in flight (ptx_options.lanes): 0 = library default (3: k_move of one batch of iterations "
-                    "overlaps k_bounce of the next); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
+                    help="launch sets in flight (ptx_options.lanes): 0 = library default (3: kernels of different batches of iterations "
+                    "fill each other's tails); 1 = one at a time, kernels back to back (what the roofline leg always uses, "
                     "because a kernel's duration is only meaningful when it has the GPU to itself)")
     args = ap.parse_args()
 

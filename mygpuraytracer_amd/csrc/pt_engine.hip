@@ -102,7 +102,7 @@ static_assert(sceneTableWords(1, 1, 1) % 4 == 0 && sceneTableWords(12, 7, 7) % 4
 static_assert((6 * TILE) % 2 == 0 && (8 * TILE) % 2 == 0, "tileIntersect's 64-bit keys and lists must be 8-byte aligned inside the record buffer");
 
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
-// k_bounce in tile order before k_move sorts it.
+// k_bounce in tile order; the sort exists only as the chunk-local index in their lsrc / lidx arrays plus the run tables.
 struct PathSoA {
     // field k of the floats starts at f + k * stride, of the ints at i + k * stride (stride = segments x capacity; a
     // segment's part of a field starts seg * capacity further).  Kept as base + stride rather than 17 pointers: a kernel
@@ -1506,7 +1506,7 @@ struct ptx_tracer {
     // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
     bool ktiming = false;
     std::vector<hipEvent_t> kev;                         // pairs (start, stop)
-    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh, 3 k_move
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh / k_finish, 3 unused (was k_move)
     size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;
@@ -2189,7 +2189,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         }
     }
     t->kmax = kmax;
-    // three launch sets in flight (one per stream) unless told otherwise: k_move of one overlaps k_bounce of another and
+    // three launch sets in flight (one per stream) unless told otherwise: kernels of different sets overlap and
     // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per
     // iteration); also with one iteration per launch set, i.e. frames so large that only one fits the memory rule above
     // (7680 x 4320: 6.2 -> 4.75 ms per iteration); needs the per-iteration radiance buffers
