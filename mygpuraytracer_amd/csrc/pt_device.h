@@ -1079,6 +1079,9 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
 }
 
 // What the winning key stands for: t, geom, material, normal (and texcoords when the scene uses them).
+// NO_MESH: the caller knows the winner is a cube or a sphere (pass 1 of the split bounce finishing a ray that reached no mesh box):
+// the mesh branch -- barycentrics redone, bump map -- is not compiled into that call site.
+template <bool NO_MESH = false>
 PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long key, Ray ray, bool need_uv, Hit &h) {
     h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
     if (key == KEY_NONE) return;
@@ -1089,7 +1092,7 @@ PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long ke
     h.t = __int_as_float((int)(uint32_t)(key >> 32));
     h.geom = g;
     h.mat = __float_as_int(G[37]);
-    if (type == G_OBJ) {
+    if (!NO_MESH && type == G_OBJ) {
         Cand c;
         c.face = (int)aux; c.u = 0.f; c.v = 0.f;
         const DGeom &geom = sc.geoms[g];

@@ -839,7 +839,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                     if (tid == 0) (p.tile_done + (size_t)p.maxTiles * seg)[tile] = finish_here ? 1 : 0;
                 }
                 if (finish_here) {
-                    if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
+                    if (alive) decodeKey<true>(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
                                          p.uses_uv != 0, hit);
                     goto classify;
                 }
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                     }
                     if (is_cand) alive = false;                                  // not part of pass 1's ranking and records
                 }
-                if (alive) decodeKey(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
+                if (alive) decodeKey<true>(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
                                      p.uses_uv != 0, hit);
                 goto classify;
             } else if (MODE == 2) {
