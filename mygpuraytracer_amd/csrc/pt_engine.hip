@@ -566,7 +566,10 @@ __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, i
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
 constexpr int SPLIT_MAX_MESHES = 2;                  // meshes per scene the split mesh search handles (2 bits of count per ray)
-constexpr int QCAP = 4 * TILE;                       // LDS queue entries of MODE 1, behind the record buffer, + its two counters
+#ifndef PT_QCAP
+#define PT_QCAP (4 * TILE)
+#endif
+constexpr int QCAP = PT_QCAP;                        // LDS queue entries of MODE 1, behind the record buffer, + its two counters
 constexpr int QUEUE_WORDS = QCAP + 4;
 // MODE 1: LDS queue -> global queue of the segment (all threads of the workgroup; uniform call)
 __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const uint32_t *qbuf, int32_t *qcnt, int32_t *qbase, int tid) {
