@@ -223,7 +223,7 @@ struct BounceParams {
     float *image;
     int32_t iter, traceDepth, bounce;      // bounce = index b of the intersect stage done by this launch
     int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
-    // split mesh search (MODE 1 / 2 of k_bounce, k_mesh in between): per-ray keys, the queue of (ray, mesh) pairs
+    // split mesh search (MODE 1 / 2 of k_bounce, k_mesh in between): per-ray keys, the queue of parked rays (their stage slots)
     unsigned long long *keys; uint32_t *items; int32_t *item_count;
     size_t seg_keys, seg_items;            // per-segment strides of keys / items; item_count has one int per segment
     int32_t *tile_done;                    // split first bounce: [segment][tile] 1 = pass 1 finished the tile (no ray of it reaches a mesh's box)
@@ -565,7 +565,6 @@ __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, i
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
-constexpr int SPLIT_MAX_MESHES = 2;                  // meshes per scene the split mesh search handles (2 bits of count per ray)
 #ifndef PT_QCAP
 #define PT_QCAP (4 * TILE)
 #endif
@@ -584,11 +583,11 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 }
 
 // MODE 0: the whole bounce.  Scenes with BVH meshes split it so that the mesh search -- few rays of a tile, each a long
-// chain of dependent node visits -- does not hold the tile's other waves at a barrier: MODE 1 does everything up to the
-// best hit among cubes and spheres and parks the ray (origin, direction, colour, pixel in the stage arrays of its own
-// tile slot, the key in `keys`) plus one queue entry per (ray, mesh) candidate; k_mesh walks the queue with one lane
-// per entry in dense, lean waves and folds its keys in with 64-bit atomic minima; MODE 2 picks the rays up again and
-// does the rest (winner's normal, terminal cases, ranking, in-tile sort, stage write).  Same arithmetic, same bits.
+// chain of dependent node visits -- does not hold the tile's other waves at a barrier: MODE 1 does the whole bounce for the
+// rays that reach no mesh's box and, for the others, everything up to the best hit among cubes and spheres; those it parks
+// (origin, direction, colour, pixel, candidate mask in a stage slot at the top of the tile, the key in `keys`) with one queue
+// entry each; k_mesh walks the queue with one lane per parked ray in dense, lean waves, searches its meshes and finishes it;
+// MODE 2 ranks all rays of the tile (the order needs every ray's bin) and writes the sort keys.  Same arithmetic, same bits.
 // FAST: the options that are run-time values in the general kernel are compile-time constants for the common case -- no
 // textures, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
 // of field, batched radiance buffers, not the cache-filling pass -- so that every test of them, and the code behind the
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
-    uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + REC_WORDS);   // MODE 1: LDS stage of the (ray, mesh) queue, [QCAP], kept
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + REC_WORDS);   // MODE 1: LDS stage of the queue of parked rays, [QCAP], kept
     int32_t *qcnt = rec + REC_WORDS + QCAP, *qbase = qcnt + 1;        // across tiles (so not inside the record buffer)
     if (MODE == 1 && tid == 0) *qcnt = 0;
     for (int k = tid; k < 2 * nb; k += TILE) run_all[k] = 0;
@@ -866,24 +865,18 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                         stage.dx()[sa] = ray.d.x; stage.dy()[sa] = ray.d.y; stage.dz()[sa] = ray.d.z;
                         stage.cr()[sa] = ps.color.x; stage.cg()[sa] = ps.color.y; stage.cb()[sa] = ps.color.z;
                         stage.pix()[sa] = pix;
-                        stage.mg()[sa] = i;                                      // whose ray this is: k_finish writes the verdict to lsrc[i]
+                        stage.mg()[sa] = i;                                      // whose ray this is: k_mesh writes the verdict to lsrc[i]
+                        stage.nx()[sa] = __int_as_float((int)mesh_cand);         // the meshes whose boxes it reaches (bit per geom)
                         (p.keys + p.seg_keys * seg)[sa] = key;
                         k1 = K1_CAND | (myslot << 16);
                     }
-                    // queue entries go through an LDS buffer (behind the record buffer) and reach the global queue in blocks: one
-                    // global atomic per ~30 tiles instead of one per wave (a single hot counter)
-                    const int mine = (int)__popc(mesh_cand);                     // 0 .. SPLIT_MAX_MESHES
-                    const unsigned long long b0 = __ballot(mine & 1), b1 = __ballot(mine & 2);
-                    const int wtot = __popcll(b0) + 2 * __popcll(b1);
+                    // one queue entry per parked ray -- its slot; which meshes it is a candidate for travels with the ray -- through an
+                    // LDS buffer (behind the record buffer) to the global queue in blocks: one global atomic per ~50 tiles instead of
+                    // one per wave (a single hot counter)
                     int base = 0;
-                    if (lane == 0 && wtot) base = atomicAdd(qcnt, wtot);
-                    base = __builtin_amdgcn_readfirstlane(base) + wavePrefix(b0, lane) + 2 * wavePrefix(b1, lane);
-                    uint32_t m = mesh_cand;
-                    for (int j = 0; j < mine; j++) {
-                        const int g = __ffs((int)m) - 1;
-                        m &= m - 1;
-                        qbuf[base + j] = (uint32_t)sa | ((uint32_t)g << 26) | (j == 0 ? 0x80000000u : 0u);      // bit 31: the ray's first entry
-                    }
+                    if (lane == 0 && cb) base = atomicAdd(qcnt, __popcll(cb));
+                    const int qi = __builtin_amdgcn_readfirstlane(base) + wavePrefix(cb, lane);      // (lane 0's value: read by all lanes)
+                    if (is_cand) qbuf[qi] = (uint32_t)sa;
                     if (is_cand) alive = false;                                  // not part of pass 1's ranking and records
                 }
                 if (alive) decodeKey<true>(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, key, ray,
@@ -1044,7 +1037,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         __syncthreads();
         STAMP(4);        // sort through LDS + stage write
-        if (MODE == 1 && *qcnt > QCAP - TILE * SPLIT_MAX_MESHES) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: read after a barrier)
+        if (MODE == 1 && *qcnt > QCAP - TILE) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: read after a barrier)
     }
 #ifdef PT_STAMPS
     if (lane == 0 && p.stamps)
@@ -1115,40 +1108,19 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #endif
 }
 
-// Split mesh search, middle part: one lane per queued (ray, mesh) pair.  The ray is read from where MODE 1 parked it,
-// the mesh is searched (BVH or the plain loop, tables in global memory) and the result folded into the ray's key with a
-// 64-bit atomic minimum -- the same key and the same minimum as in tileIntersect, so the same winner.
-struct MeshParams {
-    DScene sc;
-    PathSoA stage;
-    unsigned long long *keys; const uint32_t *items; const int32_t *item_count;
-    size_t seg_stage, seg_keys, seg_items;
-};
-__global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const MeshParams p) {
-    const int seg = blockIdx.y;
-    const int n = p.item_count[seg];
-    const PathSoA st = soa_offset(p.stage, p.seg_stage * seg);
-    const uint32_t *items = p.items + p.seg_items * seg;
-    unsigned long long *keys = p.keys + p.seg_keys * seg;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const uint32_t item = items[k];
-        const int i = (int)(item & 0x3ffffffu), g = (int)((item >> 26) & 31u);
-        Ray r;
-        r.o = V3(st.px()[i], st.py()[i], st.pz()[i]);
-        r.d = V3(st.dx()[i], st.dy()[i], st.dz()[i]);
-        const unsigned long long key = meshKey(p.sc, p.sc.gtab, g, r, -1, pt_lds + threadIdx.x, 256);
-        if (key != KEY_NONE) atomicMin(&keys[i], key);
-    }
-}
-
-// Split mesh search, after k_mesh: one lane per PARKED ray (the queue entries that carry bit 31) finishes it -- nearest hit decoded
-// from the ray's final key, terminal cases, its record written into the slot it was parked in if it goes on -- and leaves the one
-// word pass 2 needs in lsrc[owner].  Dense lanes that all do the same thing: the dependent face / texel loads of a textured mesh
-// hit, which used to hold a whole tile at a barrier in pass 2, are hidden by the other waves here.  Scene tables from global memory.
+// Split mesh search, middle part: one lane per PARKED ray (round 3: per ray, not per (ray, mesh) pair, and the ray is finished here).
+// The ray is read from the slot pass 1 parked it in, every mesh whose box it reaches is searched (four-wide BVH walk, or the
+// plain loop for a mesh without a tree; tables in global memory) and the nearest of their keys and the key pass 1 left (cubes and
+// spheres) is the ray's hit -- the same keys and the same minimum as in tileIntersect, so the same winner.  When every lane of the
+// wave has ended its walk the wave FINISHES its rays together: hit decoded, terminal cases, the record completed in the slot the ray
+// was parked in if it goes on, and the one word pass 2 needs left in lsrc[owner].  Dense lanes that all do the same thing: the
+// dependent face / texel loads of a textured mesh hit, which held a whole tile at a barrier when pass 2 did this, hide behind the
+// other waves.  (An earlier form of the round had a kernel of its own for the finishing, k_finish, and 64-bit atomic minima for rays
+// that reach two meshes' boxes: one launch and the atomics less.)
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
+__global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams p_in, int bvh_stack) {
     BounceParams p = p_in;
-    p.sc.tri_lds = 0; p.sc.ntri_lds = 0;                    // (no LDS tables in this kernel)
+    p.sc.tri_lds = 0; p.sc.ntri_lds = 0; p.sc.bvh_stack = bvh_stack;      // (no LDS tables in this kernel; LDS = the walks' stacks)
     const int seg = blockIdx.y;
     const int iter = p.iter + seg * p.iter_stride;
     const int n = p.item_count[seg];
@@ -1157,17 +1129,24 @@ __global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
     const unsigned long long *keys = p.keys + p.seg_keys * seg;
     float *part = p.part ? p.part + p.seg_part * seg : nullptr;
     const bool batched = part != nullptr;
+    const uint32_t slots = (uint32_t)p.maxTiles * TILE;
+    const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const uint32_t item = items[k];
-        if (!(item >> 31)) continue;
-        const int sa = (int)(item & 0x3ffffffu);
-        const int owner = st.mg()[sa], pix = st.pix()[sa];
+        const int sa = (int)items[k];
+        if ((uint32_t)sa >= slots) continue;                 // (fence: a queue entry is a slot of the stage, whatever wrote it)
         Ray ray;
         ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
         ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
+        unsigned long long key = keys[sa];
+        for (uint32_t m = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask; m; m &= m - 1) {
+            const unsigned long long km = meshKey(p.sc, p.sc.gtab, __ffs((int)m) - 1, ray, -1, pt_lds + threadIdx.x, 256);
+            key = km < key ? km : key;
+        }
+        const int owner = st.mg()[sa], pix = st.pix()[sa];
+        if ((uint32_t)owner >= slots) continue;
         const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
         Hit hit;
-        decodeKey(p.sc, p.sc.gtab, keys[sa], ray, p.uses_uv != 0, hit);
+        decodeKey(p.sc, p.sc.gtab, key, ray, p.uses_uv != 0, hit);
         int bin = 0;
         bool pending = false;
         classifyPath<FIRST>(p, iter, part, batched, hit, color, pix, bin, pending);
@@ -1324,7 +1303,7 @@ __global__ void k_kat_intersect(DScene sc, int n, const HostPath *paths, HostIse
 // computeIntersections as PRODUCTION runs it, on arbitrary rays: candidate masks from the world boxes (cullMask), the tile's (ray, geom)
 // pairs pooled in LDS and tested by primKey / meshKey, 64-bit LDS minimum, winner decoded by decodeKey -- tileIntersect itself, with
 // the scene tables staged as k_bounce stages them.  SPLIT: the three pieces of the split mesh search instead -- tileIntersect<DEFER>
-// (pass 1), meshKey with the front-to-back stack traversal per (ray, mesh) candidate folded in by minimum (k_mesh), decodeKey (pass 2).
+// (pass 1), meshKey with the stack traversal for every mesh of the ray's candidate mask, folded in by minimum, and decodeKey (k_mesh).
 // A named test for the functions that the frame-level parity tests only reach through whole bounces.
 template <bool SPLIT>
 __global__ __launch_bounds__(TILE) void k_kat_tile(DScene sc, DScene scg, int n, const HostPath *paths, HostIsect *out, int uses_uv) {
@@ -1788,17 +1767,9 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
-            MeshParams mq;
-            mq.sc = t->scene();                                   // tables in global memory
-            mq.stage = bp.stage; mq.keys = bp.keys; mq.items = bp.items; mq.item_count = bp.item_count;
-            mq.seg_stage = bp.seg_stage; mq.seg_keys = bp.seg_keys; mq.seg_items = bp.seg_items;
-            // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy (62 VGPRs would allow 8 waves per
-            // SIMD, 32 entries x 256 lanes x 4 B = 32 KB per workgroup only 5): as many entries as the deepest tree needs
-            mq.sc.bvh_stack = t->bvh_stack;
-            KT(2, hipLaunchKernelGGL(k_mesh, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, mq));
-            // (pass 2 neither intersects nor sorts through LDS: scene tables and the ranking head only)
-            if (first) KT(2, hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp));
-            else KT(2, hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp));
+            // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy: as many entries as the longest walk needs
+            if (first) KT(2, hipLaunchKernelGGL(k_mesh<true>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
+            else KT(2, hipLaunchKernelGGL(k_mesh<false>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
@@ -2233,14 +2204,14 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     }
     t->seg_part = 3 * (size_t)t->cap;                 // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles
     if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * t->seg_part * nseg));
-    {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull) and a
-        // queue entry per (ray, mesh) pair in the worst case
+    {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull, <= 32 geoms: a
+        // parked ray carries one bit per mesh whose box it reaches) and a queue entry per ray in the worst case
         int nmesh = 0;
         for (int i = 0; i < ngeoms; i++) nmesh += hg[i].type == G_OBJ ? 1 : 0;
-        t->split_mesh = t->bvh_meshes > 0 && t->cull && !opt.no_mesh_split && nmesh <= SPLIT_MAX_MESHES && t->cap < (1 << 26);
-        if (getenv("PTX_DEBUG_FORCE_SPLIT")) t->split_mesh = t->cull && nmesh >= 1 && nmesh <= SPLIT_MAX_MESHES;      // timing experiments only
+        t->split_mesh = t->bvh_meshes > 0 && t->cull && !opt.no_mesh_split;
+        if (getenv("PTX_DEBUG_FORCE_SPLIT")) t->split_mesh = t->cull && nmesh >= 1;      // timing experiments only
         if (t->split_mesh) {
-            t->seg_items = (size_t)t->cap * nmesh;
+            t->seg_items = (size_t)t->cap;
             HC(hipMalloc(&t->d_keys, sizeof(unsigned long long) * (size_t)t->cap * nseg));
             HC(hipMalloc(&t->d_items, sizeof(uint32_t) * t->seg_items * nseg));
             HC(hipMalloc(&t->d_item_count, sizeof(int32_t) * nseg));

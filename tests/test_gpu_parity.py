@@ -1087,8 +1087,47 @@ def test_random_scenes_on_the_tile_path(gpu_product, O, tmp_path, seed):
     _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
 
 
+def test_split_mesh_search_with_many_meshes_per_ray(gpu_product, O, tmp_path):
+    """Five BVH meshes (the stand-in ship, overlapping boxes) and three small ones without a tree among 22 geoms: the split mesh
+    search parks a ray once, whatever the number of meshes whose boxes it reaches (a bit per geom; rounds 1-2 handled two
+    meshes per scene and fell back to the unsplit kernel beyond), and k_mesh searches them one after the other.  Frames, rays
+    per bounce and the sorted streams equal the oracle's; the unsplit kernel gives the same frame."""
+    rng = np.random.default_rng(77)
+    mats = [(1, 1, 1, 0, 0, 0, 0, 0, 0, 5), (.9, .9, .9, 0, 0, 0, 0, 0, 0, 0), (.8, .3, .3, 0, 0, 0, 0, 0, 0, 0),
+            (.3, .8, .3, 0, 0, 0, 0, 0, 0, 0), (.95, .95, .95, .95, .95, .95, 1, 0, 0, 0), (.95, .95, .95, .8, .85, .95, 0, 1, 1.5, 0)]
+    text = "".join(MAT % ((m,) + mats[m]) for m in range(len(mats))) + CAMERA_BLOCK
+    objs = ["cube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 4 .3 4", "cube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 11 .01 11",
+            "cube\nmaterial 1\nTRANS 0 10 0\nROTAT 0 0 90\nSCALE .01 11 11", "cube\nmaterial 1\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 11 11",
+            "cube\nmaterial 2\nTRANS -5 5 0\nROTAT 0 0 0\nSCALE .01 11 11", "cube\nmaterial 3\nTRANS 5 5 0\nROTAT 0 0 0\nSCALE .01 11 11"]
+    for k in range(16):
+        pos = rng.uniform([-2.5, 2.0, -2.5], [2.5, 7.0, 2.0])
+        rot = rng.uniform(-180, 180, 3)
+        if k < 5:
+            head, sc = "obj\n../models/standin_ship.obj", rng.uniform(0.8, 1.6, 3)
+        elif k < 8:
+            head, sc = "obj\n../models/cube.obj", rng.uniform(0.5, 1.5, 3)
+        else:
+            head, sc = ("sphere" if k % 2 else "cube") + "\nmaterial %d" % int(rng.integers(1, len(mats))), rng.uniform(0.4, 1.2, 3)
+        objs.append(head + "\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g" % (tuple(pos) + tuple(rot) + tuple(sc)))
+    text += "".join("OBJECT %d\n%s\n\n" % (i, o) for i, o in enumerate(objs))
+    s = _scene_from_text(gpu_product, text, tmp_path, res=(160, 96), depth=6)
+    assert s.num_geoms == 22
+    a = _vs_oracle(gpu_product, O, s, iters=3)
+    b = _vs_oracle(gpu_product, O, s, iters=3, no_mesh_split=1, batch=1)
+    assert beq(a, b)
+    _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1, lanes=1)
+    with gpu_product.Tracer(s, batch=1, lanes=1) as T:
+        T.set_kernel_timing(True)
+        T.render(1, 2)
+        assert T.kernel_times()["k_mesh"][1] > 0, "the scene must take the split mesh search"
+    d = s.dump()
+    O.set_libm(1); O.create(d, d["textures"]); O.set_options(aa=1, dof=0, sort=1, cache=1); O.pt_init()
+    with gpu_product.Tracer(s) as T:
+        check_sorted_streams(T, O, d, 6)
+
+
 def test_large_scene_beyond_the_fast_path_limits(gpu_product, O, tmp_path):
-    """A scene past every limit of the fast path -- 70 geoms (> 32: no candidate masks), four BVH meshes (> 2: the mesh
+    """A scene past every limit of the fast path -- 70 geoms (> 32: no candidate masks), four BVH meshes (without candidate masks the mesh
     search stays inside the bounce kernel), 45 materials (45 sort bins) -- takes the general code automatically and
     still equals the oracle bit for bit; so does the same scene with the mesh tree switched off."""
     rng = np.random.default_rng(4242)
