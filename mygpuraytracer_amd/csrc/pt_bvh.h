@@ -252,18 +252,20 @@ inline int bvhBuild(const float *faces15, const float *tri9, int faceStart, int 
                 W[3] = BvhWide4{(int32_t)ql[2], (int32_t)qh[0], (int32_t)qh[1], (int32_t)qh[2]};
             }
         }
-        // the stack a walk can need, exactly: descending from a wide node into one inner entry leaves at most its other inner entries
-        // on the stack -- need(w) = max over inner entries c of (inner entries of w - 1) + need(c); wide nodes were created parents
-        // first, so a sweep from the back sees every child before its parent
+        // the stack a walk can need, exactly: taking one entry of a wide node (leaf or inner -- the walk defers leaves like inner
+        // entries) leaves at most its other entries on the stack -- need(w) = (entries of w - 1) + max over inner entries c of need(c);
+        // wide nodes were created parents first, so a sweep from the back sees every child before its parent
         const int nw = (int)(out.wide.size() / 4) - wbase;
         std::vector<int> need((size_t)std::max(nw, 1), 0);
         for (int w = nw - 1; w >= 0; w--) {
             const BvhWide4 *W = &out.wide[(size_t)(wbase + w) * 4];
             const int32_t refs[4] = {W[1].c, W[1].d, W[2].a, W[2].b};
-            int inner = 0, deepest = 0;
-            for (int k = 0; k < 4; k++)
-                if (refs[k] >= 0) { inner++; deepest = std::max(deepest, need[(size_t)(refs[k] - wbase)]); }
-            need[(size_t)w] = inner ? inner - 1 + deepest : 0;
+            int entries = 0, deepest = 0;
+            for (int k = 0; k < 4; k++) {
+                if (refs[k] != -1) entries++;
+                if (refs[k] >= 0) deepest = std::max(deepest, need[(size_t)(refs[k] - wbase)]);
+            }
+            need[(size_t)w] = entries ? entries - 1 + deepest : 0;
         }
         if (wroot_out) *wroot_out = wroot;
         if (wneed_out) *wneed_out = (nw ? need[0] : 0) + 1;

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mygpuraytracer_amd as pt
 from conftest import ensure_standin_assets
 ensure_standin_assets()
-s = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=(3840, 2160), depth=8); s.apply_runcuda_camera()
+SCENE = sys.argv[1] if len(sys.argv) > 1 else "cornellSpaceship20k.txt"
+ITERS = int(os.environ.get("C5_ITERS", "64"))
+s = pt.Scene(os.path.join(ROOT, "scenes", SCENE), res=(3840, 2160), depth=8); s.apply_runcuda_camera()
 with pt.Tracer(s, depth_of_field=1, lanes=1) as T:
-    T.render(1, 64); T.synchronize()
-    print("loop ms per iteration", T.last_loop_ms() / 64)
+    T.render(1, ITERS); T.synchronize()
+    print("loop ms per iteration", T.last_loop_ms() / ITERS)

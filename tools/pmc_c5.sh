@@ -1,0 +1,12 @@
+#!/bin/bash
+# SQ counter pass over the C5-shaped run (tools/gpu_c5_profile.py, 20 448-triangle mesh, 16 iterations, one launch set at a time):
+# what bounds k_mesh.  bash tools/pmc_c5.sh TAG  ->  gpurun_out/pmc_c5_TAG_a/ ; condense with tools/collect_sq_c5.py TAG
+set -e
+TAG=$1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+export C5_ITERS=16
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
+rm -rf $R/gpurun_out/pmc_c5_${TAG}_a
+rocprofv3 --pmc $A --output-format csv -d $R/gpurun_out/pmc_c5_${TAG}_a -- python3 $R/tools/gpu_c5_profile.py > $R/gpurun_out/pmc_c5_${TAG}_a.log 2>&1
+echo "pass a done"
