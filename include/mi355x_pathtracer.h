@@ -253,7 +253,8 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
                         int32_t *face_bvh, float *t_bvh, int64_t *stats4);
 /* CPU-only: node visits of the last ptx_debug_bvh_check -- skip-link walk, front-to-back binary walk, four-wide walk (nodes),
    the stack entries the four-wide walk of that tree can need, the sum over groups of 64 consecutive rays of the longest four-wide
-   walk in the group and the number of groups (what a wave of one-lane-per-ray walks costs); [6], [7] unused */
+   walk in the group and the number of groups (what a wave of one-lane-per-ray walks costs), triangles tested by the four-wide walk;
+   [7] unused */
 int ptx_debug_bvh_visits(int64_t out8[8]);
 /* zeros unless the library was built with -DPT_STAMPS (in-kernel phase timing, never in the shipped build) */
 int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out48[48]);

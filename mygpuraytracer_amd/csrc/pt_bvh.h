@@ -23,7 +23,8 @@
 //      triangle for reaches every box around that triangle WIDENED BY 64 u (D + L) / kappa.  The traversal widens every
 //      slab by  slack = 2^11 u (|o - c| + 4 R)  (c, R: centre and half diagonal of the root box; D <= |o - c| + R, L <= 2R;
 //      bvhSlack / slabEntry in pt_device.h), on top of the static inflation below and of the slab test's own rounding
-//      (4 u (|o| + |box|) per plane, inside the 4 R term).  Hence:
+//      (4 u (|o| + |box|) per plane, inside the 4 R term; the four-wide walk adds the slack to the origin term before the fused
+//      multiply-add instead of after it -- one more rounding of that size per plane, 5 u, inside the same term).  Hence:
 //
 //          for EVERY ray, at ANY distance, the tree returns the loop's face and distance whenever each triangle the loop
 //          accepts is conditioned no worse than kappa >= 2^-5 (about 1.8 degrees off grazing for a right-angled triangle).

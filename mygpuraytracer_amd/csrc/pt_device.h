@@ -639,6 +639,9 @@ PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__
     // per vector instruction before).  A hit prunes through tmin as before: every box is tested against the best distance when its
     // node is visited.
     constexpr int32_t DONE = (int32_t)0x80000000;           // (a leaf reference with count 0: no leaf is encoded like this)
+    const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;       // (1/d is finite and not 0: makeRaySlab)
+    const float enx = -(rs.ox + rs.sx), eny = -(rs.oy + rs.sy), enz = -(rs.oz + rs.sz);
+    const float efx = rs.sx - rs.ox, efy = rs.sy - rs.oy, efz = rs.sz - rs.oz;
     int sp = 0, n = wroot;
     for (;;) {
         while (n >= 0) {
@@ -652,15 +655,20 @@ PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__
             const float none = __builtin_inff();
             float t0 = none, t1 = none, t2 = none, t3 = none;
             int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+            // which of an entry's two planes per axis the ray meets first is the same for all four entries: the word that holds the
+            // NEAR planes' grid coordinates is picked once per node (by the sign of 1/d), and the slack is inside the origin terms
+            // (en = -(o/d + slack/|d|), ef = -(o/d - slack/|d|)): a box is 12 conversions, 12 fused multiply-adds, a max3, a min3 and
+            // three compares -- slabEntry's planes, interval and three reasons to skip, without its minima / maxima per axis.
+            const uint32_t nxw = negx ? hx : lx, fxw = negx ? lx : hx, nyw = negy ? hy : ly, fyw = negy ? ly : hy, nzw = negz ? hz : lz, fzw = negz ? lz : hz;
+            const float tcut = tmin * 1.0001f;
 #define PT_WIDE_ENTRY(K, REF, TK, CK)                                                                                          \
             if (REF != -1) {                                                                                                   \
-                BvhQuad A, B;                                                                                                  \
-                A.x = __builtin_fmaf((float)((lx >> (8 * K)) & 255u), sx, ox); B.x = __builtin_fmaf((float)((hx >> (8 * K)) & 255u), sx, ox); \
-                A.y = __builtin_fmaf((float)((ly >> (8 * K)) & 255u), sy, oy); B.y = __builtin_fmaf((float)((hy >> (8 * K)) & 255u), sy, oy); \
-                A.z = __builtin_fmaf((float)((lz >> (8 * K)) & 255u), sz, oz); B.z = __builtin_fmaf((float)((hz >> (8 * K)) & 255u), sz, oz); \
-                A.w = B.w = 0;                                                                                                 \
-                float tn;                                                                                                      \
-                if (slabEntry(A, B, rs, tmin, tn)) { TK = tn; CK = REF; }                                                      \
+                const float ax = __builtin_fmaf((float)((nxw >> (8 * K)) & 255u), sx, ox), bx = __builtin_fmaf((float)((fxw >> (8 * K)) & 255u), sx, ox); \
+                const float ay = __builtin_fmaf((float)((nyw >> (8 * K)) & 255u), sy, oy), by = __builtin_fmaf((float)((fyw >> (8 * K)) & 255u), sy, oy); \
+                const float az = __builtin_fmaf((float)((nzw >> (8 * K)) & 255u), sz, oz), bz = __builtin_fmaf((float)((fzw >> (8 * K)) & 255u), sz, oz); \
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ax, rs.ix, enx), __builtin_fmaf(ay, rs.iy, eny)), __builtin_fmaf(az, rs.iz, enz)); \
+                const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bx, rs.ix, efx), __builtin_fmaf(by, rs.iy, efy)), __builtin_fmaf(bz, rs.iz, efz)); \
+                if (!((tf < tn) || (tf < 0.0f) || (tn > tcut))) { TK = tn; CK = REF; }                                         \
             }
             PT_WIDE_ENTRY(0, r0, t0, c0)
             PT_WIDE_ENTRY(1, r1, t1, c1)
@@ -684,6 +692,7 @@ PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__
         if (n == DONE) return tmin;
         {   // a leaf: its triangles
             const int count = (int)(((uint32_t)n >> 24) & 0x7fu), first = n & 0x00ffffff;
+            if (visited) *visited += count << 16;         // (triangle tests, counted apart from the node visits in the low half)
             for (int j = 0; j < count; j++) {
                 const float *T = tris + (size_t)(first + j) * BVH_TRI;
                 const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);

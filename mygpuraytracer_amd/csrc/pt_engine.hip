@@ -2708,7 +2708,7 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
     int wroot = -1, wneed = 0;
     const int root = bvhBuild(faces15, tri9.data(), 0, nfaces, bb, &depth, &wroot, &wneed);
     std::vector<int32_t> wstack((size_t)std::max(wneed, 1) + 1, 0x7fffffff);      // (+ a guard word: the walk must never reach it)
-    long long visited = 0, visited_ordered = 0, visited_wide = 0, mismatches = 0, group_max = 0, sum_group_max = 0, groups = 0;
+    long long visited = 0, visited_ordered = 0, visited_wide = 0, mismatches = 0, group_max = 0, sum_group_max = 0, groups = 0, tris_wide = 0;
     for (int i = 0; i < nrays; i++) {
         const vec3 o = V3(rays6[i * 6 + 0], rays6[i * 6 + 1], rays6[i * 6 + 2]);
         const vec3 d = normalize(V3(rays6[i * 6 + 3], rays6[i * 6 + 4], rays6[i * 6 + 5]));
@@ -2728,8 +2728,9 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
             int f3, vis3 = 0;
             float e0, e1;
             const float t3 = bvhNearestWide(bb.nodes.data(), bb.wide.data(), bb.tris.data(), root, wroot, o, d, f3, e0, e1, wstack.data(), 1, &vis3);
-            visited_wide += vis3;
-            group_max = std::max(group_max, (long long)vis3 / 4);
+            visited_wide += vis3 & 0xffff;
+            tris_wide += vis3 >> 16;
+            group_max = std::max(group_max, (long long)(vis3 & 0xffff) / 4);
             if (i % 64 == 63 || i == nrays - 1) { sum_group_max += group_max; group_max = 0; groups++; }
             if (wstack[(size_t)std::max(wneed, 1)] != 0x7fffffff) mismatches += 1000000;      // the walk overran the stack bound the builder computed
             if (f3 != f1 || memcmp(&t3, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&e0, &b0, 4) != 0 || memcmp(&e1, &b1, 4) != 0))) mismatches++;
@@ -2739,12 +2740,12 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
     }
     if (stats4) { stats4[0] = (int64_t)(bb.nodes.size() / 2); stats4[1] = (int64_t)(bb.tris.size() / BVH_TRI); stats4[2] = visited; stats4[3] = mismatches; }
     g_bvh_visits[0] = visited; g_bvh_visits[1] = visited_ordered; g_bvh_visits[2] = visited_wide / 4; g_bvh_visits[3] = wneed;
-    g_bvh_visits[4] = sum_group_max; g_bvh_visits[5] = groups;
+    g_bvh_visits[4] = sum_group_max; g_bvh_visits[5] = groups; g_bvh_visits[6] = tris_wide;
     return PTX_OK;
 }
 
 // node visits of the last ptx_debug_bvh_check: skip-link walk, front-to-back binary walk, four-wide walk (nodes), wide stack need,
-// sum over groups of 64 consecutive rays of the longest four-wide walk in the group, number of groups
+// sum over groups of 64 consecutive rays of the longest four-wide walk in the group, number of groups, triangles the four-wide walk tested
 int ptx_debug_bvh_visits(int64_t out8[8]) {
     if (!out8) return set_error(PTX_ERR_INVALID, "null argument");
     for (int k = 0; k < 8; k++) out8[k] = g_bvh_visits[k];
