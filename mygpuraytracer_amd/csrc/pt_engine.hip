@@ -919,22 +919,25 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         // index) and among the stored ones (-> storage position)
         int r_all = 0, r_scat = 0;
         {
-            unsigned long long remaining = __ballot(alive);
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            while (remaining) {
-                int leader = __ffsll((long long)remaining) - 1;
-                int b = __builtin_amdgcn_readlane(bin, leader);      // (leader is wave-uniform: no LDS round trip as __shfl would make)
-                unsigned long long m_all = __ballot(alive && bin == b);
-                unsigned long long m_scat = __ballot(pending && bin == b);
-                if (alive && bin == b) {
-                    r_all = __popcll(m_all & lt);
-                    r_scat = __popcll(m_scat & lt);
+            // a lane's bin as ONE integer per question (-1: not part of it): a bin's lanes are then a single v_cmp_eq into a scalar pair
+            // (a ballot of `flag && bin == b` makes the compiler materialise the flag first), and the rank among them two v_mbcnt: 15
+            // vector instructions per bin that occurs in the wave instead of 28.  (Visiting EVERY bin in turn instead -- no readlane,
+            // no find-first -- is 13 per bin and loses: camera rays see two or three of the eight bins.)
+            const int abin = alive ? bin : -1, pbin = pending ? bin : -1;
+            {
+                unsigned long long remaining = __builtin_amdgcn_uicmp((uint32_t)abin, 0xffffffffu, 33);       // (alive lanes)
+                while (remaining) {
+                    int leader = __ffsll((long long)remaining) - 1;
+                    int b = __builtin_amdgcn_readlane(abin, leader);      // (leader is wave-uniform: no LDS round trip as __shfl would make)
+                    const unsigned long long m_all = __builtin_amdgcn_uicmp((uint32_t)abin, (uint32_t)b, 32), m_scat = __builtin_amdgcn_uicmp((uint32_t)pbin, (uint32_t)b, 32);
+                    const int ra = wavePrefix(m_all, lane), rs = wavePrefix(m_scat, lane);
+                    if (abin == b) { r_all = ra; r_scat = rs; }
+                    if (lane == leader) {
+                        w_all[wave * nb + b] = __popcll(m_all);
+                        w_scat[wave * nb + b] = __popcll(m_scat);
+                    }
+                    remaining &= ~m_all;
                 }
-                if (lane == leader) {
-                    w_all[wave * nb + b] = __popcll(m_all);
-                    w_scat[wave * nb + b] = __popcll(m_scat);
-                }
-                remaining &= ~m_all;
             }
         }
         STAMP(12);       // (ranking: ballots)
@@ -1326,10 +1329,13 @@ __global__ __launch_bounds__(TILE) void k_kat_tile(DScene sc, DScene scg, int n,
         h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = h.v = 0.f; h.geom = 0; h.mat = 0;
         unsigned long long key = KEY_NONE;
         uint32_t mesh_cand = 0;
+#ifdef PT_STAMPS
+        unsigned long long st_acc[16] = {0}, st_t0 = 0;        // (the phase-timing build: this kernel's stamps go nowhere)
+#endif
         if (!SPLIT) {
-            tileIntersect<false>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand);
+            tileIntersect<false>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
         } else {
-            tileIntersect<true>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand);
+            tileIntersect<true>(sc, alive, ray, uses_uv != 0, h, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
             for (uint32_t m = mesh_cand; m; m &= m - 1) {
                 const unsigned long long k = meshKey(scg, scg.gtab, __ffs((int)m) - 1, ray, -1, stack + tid, TILE);
                 key = k < key ? k : key;

@@ -14,7 +14,7 @@ s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=8); s.apply_run
 T = pt.Tracer(s, depth_of_field=1 if "Spaceship" in scene else 0, lanes=1)
 L = pt.load_library()
 L.ptx_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-out = np.zeros(32, np.uint64)
+out = np.zeros(48, np.uint64)
 T.render(1, 16); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
 T.render(17, 64); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
 names = {0: "load+shade/gen", 1: "isect-rest", 2: "classify+deposit", 3: "ranking", 4: "sort+write", 5: "cull+list", 6: "items", 7: "decode", 11: "load-wait", 12: "rank-ballots", 13: "rank-wait1", 14: "rank-counts"}
