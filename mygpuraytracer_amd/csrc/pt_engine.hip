@@ -481,13 +481,17 @@ __device__ __forceinline__ void classifyPath(const BounceParams &p, int iter, fl
     }
 }
 
-// inclusive prefix sum over the lanes of a wave
+// inclusive prefix sum over the lanes of a wave, in the vector ALU's own lane network (DPP): four shifted adds inside the rows of 16
+// lanes, then lane 15 of a row broadcast to the next row (rows 1 and 3) and lane 31 to the upper half -- six dependent vector
+// instructions.  (__shfl_up goes through the LDS crossbar: six ds_bpermute round trips, 0.3 us on a tile's critical path each time.)
 __device__ __forceinline__ int waveInclusiveScan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -963,12 +967,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                     run_all[ln] += ca;
                     run_scat[ln] += cs;
                 }
-                int inc = cs;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int a = __shfl_up(inc, off);
-                    if (ln >= off) inc += a;
-                }
+                const int inc = waveInclusiveScan(cs, ln);
                 if (ln < nb) toff[ln] = inc - cs;
                 if (ln == nb - 1) toff[nb] = inc;
             }
