@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (MODE == 1 && *qcnt > QCAP - TILE) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: read after a barrier)
     }
 #ifdef PT_STAMPS
-    if (lane == 0 && p.stamps)
+    if (lane == 0 && p.stamps && (blockIdx.x & 15) == 0)           // (a sample of the workgroups: atomics of all of them on 16 words outlast a short kernel)
         for (int k = 0; k < 16; k++) atomicAdd(&p.stamps[(FIRST ? 0 : 16) + k], st_acc[k]);
 #endif
 #ifdef PT_WGCLOCK

@@ -11,12 +11,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import ensure_standin_assets
 ensure_standin_assets()
 s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=8); s.apply_runcuda_camera()
-T = pt.Tracer(s, depth_of_field=1 if "Spaceship" in scene else 0, lanes=1)
+WORLD = int(os.environ.get("TILE_WORLD", "1"))          # > 1: rank 3's tile of such a split, in 20-step calls (the latency-bound case)
+opt = dict(tile_rows=8, tile_rank=3 % WORLD, tile_world=WORLD) if WORLD > 1 else dict(lanes=1)
+T = pt.Tracer(s, depth_of_field=1 if "Spaceship" in scene else 0, **opt)
 L = pt.load_library()
 L.ptx_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
 out = np.zeros(48, np.uint64)
 T.render(1, 16); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
-T.render(17, 64); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
+if WORLD > 1:
+    tot = np.zeros(48, np.uint64)
+    for rep in range(20):
+        T.render(100 + 20 * rep, 20); T.synchronize(); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p)); tot += out
+    out = tot
+else:
+    T.render(17, 64); L.ptx_debug_read_stamps(T.h, out.ctypes.data_as(C.c_void_p))
 names = {0: "load+shade/gen", 1: "isect-rest", 2: "classify+deposit", 3: "ranking", 4: "sort+write", 5: "cull+list", 6: "items", 7: "decode", 11: "load-wait", 12: "rank-ballots", 13: "rank-wait1", 14: "rank-counts"}
 for base, tag in ((0, "k_bounce<first>"), (16, "k_bounce")):
     tot = float(out[base:base + 8].sum() + out[base + 11:base + 15].sum())
