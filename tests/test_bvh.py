@@ -74,6 +74,26 @@ def test_hull_random_rays(product):
     assert st[2] / len(rays) < 400            # the tree is actually pruning (the loop would visit 9216 triangles per ray)
 
 
+def test_walk_statistics_of_the_last_check(product):
+    """ptx_debug_bvh_visits: what the three walks cost on the rays of the last check -- the figures k_mesh's traversal was tuned
+    by.  The four-wide walk visits fewer nodes than the binary front-to-back walk, that one fewer than the skip-link walk; its
+    stack bound is inside what k_mesh provides; leaves hold at most four triangles, so a walk tests a handful, not hundreds."""
+    rng = np.random.default_rng(17)
+    faces = hull(32, 64)                      # 4096 triangles
+    rays = rays_around(rng, 6400, 5.0, 1.2)
+    assert_same(run_check(product, faces, rays))
+    L = product.load_library()
+    v = np.zeros(8, np.int64)
+    L.ptx_debug_bvh_visits.restype = C.c_int
+    L.ptx_debug_bvh_visits.argtypes = [C.c_void_p]
+    assert L.ptx_debug_bvh_visits(v.ctypes.data) == 0
+    skip, ordered, wide, need, group_max, groups, tris = (int(x) for x in v[:7])
+    assert 0 < wide < ordered < skip
+    assert 1 <= need <= 32
+    assert groups == 100 and wide <= 64 * group_max          # (per 64 rays the longest walk bounds the sum)
+    assert 0 < tris < 40 * len(rays)
+
+
 def test_triangle_soup_and_ties(product):
     rng = np.random.default_rng(11)
     n = 3000
