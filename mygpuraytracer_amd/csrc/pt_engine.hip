@@ -744,6 +744,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     };
     int32_t *ccnt = qcnt + 2;                                   // MODE 1: candidates of the tile so far (LDS)
     int32_t k1_next = 0;                                        // MODE 2: the next tile's word, requested one tile ahead
+    if (MODE == 2) {                                            // (its histogram: zeroed here once, then after every tile's ranking)
+        for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
+        __syncthreads();
+    }
     if (MODE == 2 && !FIRST && tile0 < tile1 && tile0 * TILE + tid < n_in) k1_next = ld_u(soa_fresh(stage_k).lsrc(), (uint32_t)(tile0 * TILE + tid) << 2);
     for (int tile = tile0; tile < tile1; tile++) {
 #ifdef PT_STAMPS
@@ -758,7 +762,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA stage = soa_fresh(stage_k);      // field addresses are formed where they are used
         PathState ps;
         int pix = 0;                 // slot among the owned pixels: what the path carries instead of the pixel index
-        for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;        // ranking histogram (read after later barriers)
+        // ranking histogram (read after later barriers).  The ranking pass (MODE 2) has no intersection whose barriers would separate
+        // this from the ballots' writes: it zeroes the histogram right after a tile's LAST read of it instead (below), and once before
+        // its first tile -- three barriers per tile instead of five for a kernel that is a chain of barriers and little else.
+        if (MODE != 2) for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
         int32_t k1 = 0;
@@ -887,7 +894,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                                      p.uses_uv != 0, hit);
                 goto classify;
             } else if (MODE == 2) {
-                __syncthreads();                                  // histogram zeroed
+                rec[tid] = -1;                                    // this slot's key, until a stored path claims the slot (keybuf below;
+                                                                  // the barriers of the ranking lie between this and the claims)
             } else if (p.sc.cull) {
                 // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 72 registers.  The thread's own state
                 // that is only needed again after the intersection -- throughput colour and pixel slot; the ray itself is in
@@ -994,12 +1002,12 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         STAMP(3);        // ranking + counts
         if (MODE == 2) {                 // the records lie in their slots already (pass 1, or above): only the keys are left,
             int32_t *keybuf = rec;       // one per SLOT (through LDS: a path's slot is not its thread), -1 where no record lies
-            keybuf[tid] = -1;
-            __syncthreads();
+            for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;      // (w_all / w_scat were last read before the barriers above;
+                                                                               // the barrier below is in front of the next tile's ballots)
             if (pending) keybuf[myslot] = stage_key(bin, r_all, r_scat);
             __syncthreads();
             st_u(soa_fresh(stage_k).idx(), (uint32_t)i << 2, keybuf[tid]);
-            continue;                    // (w_all / w_scat were last read before the barriers above: the next tile may zero them)
+            continue;
         }
         if (MODE == 1 && pass1_partial && i < n_in) {
             if (alive) k1 = K1_ALIVE | bin | (pending ? K1_PEND | ((toff[bin] + r_scat) << 16) : 0);
