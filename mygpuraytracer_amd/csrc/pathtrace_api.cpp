@@ -147,7 +147,7 @@ void pathtraceFree() {          // safe before init and idempotent, as main.cpp:
     g_tracer = nullptr;
 }
 
-void pathtrace(void *pbo, int frame, int iter) {
+void mi355x::pathtrace_raw(void *pbo, int frame, int iter) {
     (void)frame;                 // unused by the reference as well
     if (!g_tracer || !hst_scene) { fprintf(stderr, "pathtrace called before pathtraceInit\n"); exit(EXIT_FAILURE); }
     // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
@@ -176,10 +176,14 @@ void pathtrace(void *pbo, int frame, int iter) {
 }
 
 // apps/src/pathtrace.cu:673-685: the denoised frame in state.output -> the pbo, scaled by 255 and clamped, no division by iter
-void sendToGPU(void *pbo, int iter) {
+void mi355x::sendToGPU_raw(void *pbo, int iter) {
     (void)iter;                  // passed to the kernel but unused there as well (apps/src/pathtrace.cu:96-116)
     if (!g_tracer || !hst_scene) { fprintf(stderr, "sendToGPU called before pathtraceInit\n"); exit(EXIT_FAILURE); }
     check(ptx_write_denoised_pbo_device(g_tracer, &hst_scene->state.output[0].x, pbo), "sendToGPU");
 }
+
+// the same two under the reference's names, for translation units without HIP's vector types (see pathtrace_api.h)
+void pathtrace(void *pbo, int frame, int iter) { mi355x::pathtrace_raw(pbo, frame, iter); }
+void sendToGPU(void *pbo, int iter) { mi355x::sendToGPU_raw(pbo, iter); }
 
 ptx_tracer *pathtraceHandle() { return g_tracer; }

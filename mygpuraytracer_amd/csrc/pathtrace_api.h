@@ -16,13 +16,17 @@
 #include "../../include/mi355x_pathtracer.h"
 
 // The pbo arguments are device pointers to uchar4 exactly as in the reference (the mapped GL buffer of src/main.cpp:131-135).
-// The exported functions take void* so that this header compiles -- and the calls link -- whether or not the caller's
-// translation unit has HIP's vector types (hip_runtime.h makes uchar4 a typedef of a class template, which can neither be
-// forward-declared nor be mangled the same way from a file without it).  A translation unit that HAS them (it included
-// hip_runtime.h / hip_vector_types.h before this header, as src/main.cpp's includes do through pathtrace.h's
-// <cuda_runtime.h> counterpart) also gets the reference's exact signatures, `pathtrace(uchar4 *, int, int)` and
-// `sendToGPU(uchar4 *, int)`, as inline overloads at the end of this header: taking the function's address with the
-// reference's type, or overload resolution against other pathtrace() functions, then behaves as with src/pathtrace.h:9.
+// hip_runtime.h makes uchar4 a typedef of a class template, which can neither be forward-declared nor be mangled the same way
+// from a file without it, so the EXPORTED entry points take void* (mi355x::pathtrace_raw / sendToGPU_raw, and the same two under
+// the reference's names for callers without HIP's headers).  What a translation unit SEES under the names `pathtrace` and
+// `sendToGPU` is ONE function each, never an overload set:
+//   * uchar4 known (hip_runtime.h / hip_vector_types.h included before this header, as src/main.cpp's includes do through
+//     pathtrace.h's <cuda_runtime.h> counterpart): the reference's exact signatures, `pathtrace(uchar4 *, int, int)`
+//     (src/pathtrace.h:9) and `sendToGPU(uchar4 *, int)` (apps/src/pathtrace.h:10), inline over the raw entry points --
+//     `pathtrace(NULL, 0, it)` / `pathtrace(nullptr, ...)` / `pathtrace(0, ...)` compile as they do against the reference's
+//     header, and so does taking the function's address with the reference's type;
+//   * otherwise: `pathtrace(void *, int, int)` / `sendToGPU(void *, int)`, the exported symbols themselves.
+// (Round 3 declared both at once in a HIP translation unit: a literal null pbo was then ambiguous.)
 
 namespace mi355x {
 struct vec3 { float x, y, z; };
@@ -84,11 +88,17 @@ std::vector<int> &pathtraceDevices();
 PerformanceTimer &timer();                              // src/pathtrace.h:6
 void pathtraceInit(Scene *scene);                       // src/pathtrace.h:7
 void pathtraceFree();                                   // src/pathtrace.h:8
-void pathtrace(void *pbo, int frame, int iteration);    // src/pathtrace.h:9 (uchar4 *pbo); pbo may be NULL (no preview)
-void sendToGPU(void *pbo, int iter);                    // apps/src/pathtrace.h:10 (uchar4 *pbo): state.output -> 8-bit preview in the device pbo
 ptx_tracer *pathtraceHandle();                          // the C-ABI handle behind the module-static state (device 0's with several devices)
 
-#if defined(HIP_INCLUDE_HIP_HIP_VECTOR_TYPES_H) || defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H)      // uchar4 is known here: the reference's own signatures (src/pathtrace.h:9, apps/src/pathtrace.h:10)
-inline void pathtrace(uchar4 *pbo, int frame, int iteration) { pathtrace(static_cast<void *>(pbo), frame, iteration); }
-inline void sendToGPU(uchar4 *pbo, int iter) { sendToGPU(static_cast<void *>(pbo), iter); }
+namespace mi355x {
+void pathtrace_raw(void *pbo, int frame, int iteration);   // what both spellings below run; pbo = device uchar4*, may be NULL (no preview)
+void sendToGPU_raw(void *pbo, int iter);                   // state.output -> 8-bit preview in the device pbo
+}
+#if defined(HIP_INCLUDE_HIP_HIP_VECTOR_TYPES_H) || defined(HIP_INCLUDE_HIP_AMD_DETAIL_HIP_VECTOR_TYPES_H)
+// uchar4 is known here: the reference's own signatures and nothing else under these names
+inline void pathtrace(uchar4 *pbo, int frame, int iteration) { mi355x::pathtrace_raw(static_cast<void *>(pbo), frame, iteration); }   // src/pathtrace.h:9
+inline void sendToGPU(uchar4 *pbo, int iter) { mi355x::sendToGPU_raw(static_cast<void *>(pbo), iter); }                              // apps/src/pathtrace.h:10
+#else
+void pathtrace(void *pbo, int frame, int iteration);    // src/pathtrace.h:9 (uchar4 *pbo); pbo may be NULL (no preview)
+void sendToGPU(void *pbo, int iter);                    // apps/src/pathtrace.h:10 (uchar4 *pbo)
 #endif

@@ -217,3 +217,34 @@ def test_headers_are_plain_c_and_link(product, tmp_path):
                            "-o", str(exe), "-L", libdir, "-lmi355x_pathtracer", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert out == ["64", "1", "1", "3"]
+
+
+def test_veneer_null_pbo_is_not_ambiguous(product, tmp_path):
+    """csrc/pathtrace_api.h shows ONE function under the name `pathtrace` (and `sendToGPU`) per translation unit: with HIP's
+    uchar4 known it is the reference's own signature (src/pathtrace.h:9, apps/src/pathtrace.h:10), without it the void* one.
+    Round 3 declared both in a HIP translation unit, so `pathtrace(nullptr, 0, it)` -- the call the header advertises for "no
+    preview" and tools/gpu_dropin_loop_cpp.cpp makes -- no longer compiled.  Compile-only (no GPU): the three spellings of a
+    null pbo, the address taken with the reference's type, the programs of the repo that include the veneer, and that both
+    flavours link against the library."""
+    import subprocess
+    body = ('#include "%s"\n'
+            'int main(int argc, char **) {\n'
+            '    if (argc > 1000) {\n'
+            '        pathtrace(NULL, 0, 1); pathtrace(nullptr, 0, 2); pathtrace(0, 0, 3);\n'
+            '        sendToGPU(NULL, 1); sendToGPU(nullptr, 2);\n'
+            '        %s\n'
+            '    }\n'
+            '    return pathtraceHandle() ? 1 : 0;\n}\n') % (os.path.join(ROOT, "mygpuraytracer_amd", "csrc", "pathtrace_api.h"), "%s")
+    hip = tmp_path / "with_hip.cpp"
+    hip.write_text("#include <hip/hip_runtime_api.h>\n#include <cstddef>\n" + body %
+                   "void (*f)(uchar4 *, int, int) = &pathtrace; void (*g)(uchar4 *, int) = &sendToGPU; uchar4 *p = nullptr; f(p, 0, 4); g(p, 4); pathtrace(p, 0, 5);")
+    plain = tmp_path / "without_hip.cpp"
+    plain.write_text("#include <cstddef>\n" + body % "void (*f)(void *, int, int) = &pathtrace; f(nullptr, 0, 4);")
+    libdir = os.path.dirname(product.LIB_PATH)
+    link = ["-L" + libdir, "-lmi355x_pathtracer", "-Wl,-rpath," + libdir]
+    for src, extra in ((hip, ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]), (plain, [])):
+        exe = tmp_path / (src.stem + ".exe")
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-o", str(exe), str(src)] + extra + link)
+        assert subprocess.call([str(exe)]) == 0          # (no tracer exists: pathtraceHandle() is NULL; nothing touches a GPU)
+    for prog in ("tests/veneer_check.cpp", "tools/gpu_dropin_loop_cpp.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, prog)])
