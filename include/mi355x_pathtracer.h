@@ -110,6 +110,9 @@ typedef struct ptx_stats {
     int64_t rays_total;              /* sum over all iterations since create/reset                      */
     double loop_ms_total;            /* device time of the bounce loops since create/reset              */
     int64_t iterations;
+    int64_t fenced;                  /* indices from internal tables (mesh-search queue, sort index) that the kernels found out of
+                                        range and skipped or clamped instead of faulting, since create/reset.  Always 0: anything else
+                                        means corrupted internal state (and a wrong pixel somewhere) -- report it                      */
 } ptx_stats;
 
 typedef struct ptx_tracer ptx_tracer;     /* opaque: one scene on one device */

@@ -66,7 +66,7 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("bounces", C.c_int32), ("rays_per_bounce", C.c_int64 * 64), ("rays_total", C.c_int64),
-                ("loop_ms_total", C.c_double), ("iterations", C.c_int64)]
+                ("loop_ms_total", C.c_double), ("iterations", C.c_int64), ("fenced", C.c_int64)]
 
 
 def build_library(force=False):
@@ -409,7 +409,7 @@ class MultiTracer:
         s = Stats()
         _check(self.lib.ptx_multi_get_stats(self.h, C.byref(s)), "ptx_multi_get_stats")
         return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
-                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations))
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced))
 
 
 class Tracer:
@@ -606,7 +606,7 @@ class Tracer:
         s = Stats()
         _check(self.lib.ptx_get_stats(self.h, C.byref(s)), "ptx_get_stats")
         return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
-                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations))
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced))
 
     # --- per-stage entry points used by the parity tests --------------------------------------------------
     def geom_test(self, gi, rays):

@@ -247,7 +247,14 @@ struct BounceParams {
                                            // (k_gather adds the segments to the image in iteration order)
     // first-bounce cache fill (iter 1, AA and DoF off): bounce-0 light hits are replayed on later iterations
     int32_t *emit_count; int32_t *emit_pix; float *emit_rgb;
+    // Fences that report.  Every index the kernels take from a table another launch wrote -- a queue entry of the split mesh search,
+    // a parked ray's owner, an entry of the local index, a sorted position's place in it -- is checked against `fence_slots` (the
+    // stage's capacity, maxTiles x TILE) before it becomes an address: a bad one is skipped or clamped, so it costs a wrong pixel and
+    // not a fault, and is COUNTED here (ptx_stats.fenced, 0 in every test): a wrong pixel is never the only symptom.
+    unsigned long long *fenced;
+    uint32_t fence_slots;
 };
+__device__ __forceinline__ void fence_report(const BounceParams &p) { atomicAdd(p.fenced, 1ull); }
 
 __device__ __forceinline__ int sum_totals(const int32_t *t, int n) {
     int s = 0;
@@ -715,7 +722,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #pragma unroll
                 for (int st = WIN / 2; st; st >>= 1) k += win[k + st] <= jp ? st : 0;      // last run that starts at or before jp
                 // (the clamp cannot bite while the tables are consistent: it is there so that no gather address depends on that)
-                li4 = (uint32_t)min(win[2 * (WIN + 1) + k] + (jp - win[k]), p.maxTiles * TILE - 1) << 2;
+                const uint32_t li = (uint32_t)(win[2 * (WIN + 1) + k] + (jp - win[k]));
+                if (__builtin_expect(li >= p.fence_slots, 0)) fence_report(p);
+                li4 = min(li, p.fence_slots - 1u) << 2;
                 idx_base = win[WIN + 1 + k];
                 done = true;
             }
@@ -731,7 +740,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA in = soa_fresh(in_k);
         // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
         // slot of that bounce's stage and the path's rank inside its run
-        const uint32_t j4 = min((uint32_t)ld_u(in.lsrc(), li4), (uint32_t)(p.maxTiles * TILE - 1)) << 2;
+        const uint32_t j = (uint32_t)ld_u(in.lsrc(), li4);
+        if (__builtin_expect(j >= p.fence_slots, 0)) fence_report(p);
+        const uint32_t j4 = min(j, p.fence_slots - 1u) << 2;
         r.idx = idx_base + ld_u(in.lidx(), li4);
 #pragma unroll
         for (int k = 0; k < 12; k++) r.f[k] = ld_u(in.field(k), j4);
@@ -1139,11 +1150,11 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
     const unsigned long long *keys = p.keys + p.seg_keys * seg;
     float *part = p.part ? p.part + p.seg_part * seg : nullptr;
     const bool batched = part != nullptr;
-    const uint32_t slots = (uint32_t)p.maxTiles * TILE;
+    const uint32_t slots = p.fence_slots;
     const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int sa = (int)items[k];
-        if ((uint32_t)sa >= slots) continue;                 // (fence: a queue entry is a slot of the stage, whatever wrote it)
+        if ((uint32_t)sa >= slots) { fence_report(p); continue; }      // (fence: a queue entry is a slot of the stage, whatever wrote it)
         Ray ray;
         ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
         ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
@@ -1153,7 +1164,7 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
             key = km < key ? km : key;
         }
         const int owner = st.mg()[sa], pix = st.pix()[sa];
-        if ((uint32_t)owner >= slots) continue;
+        if ((uint32_t)owner >= slots) { fence_report(p); continue; }
         const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
         Hit hit;
         decodeKey(p.sc, p.sc.gtab, key, ray, p.uses_uv != 0, hit);
@@ -1493,7 +1504,8 @@ struct ptx_tracer {
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
-    int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total
+    int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total, [65] = fenced indices (BounceParams::fenced)
+    uint32_t fence_slots = 0;                            // = cap; PTX_DEBUG_FENCE_SLOTS lowers it (test of the counter: entries beyond it are fenced)
     int maxBounces = 0;
     bool cache_valid = false;
     int64_t iterations = 0;
@@ -1773,6 +1785,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.part = batched ? t->d_part + seg0 * bp.seg_part : nullptr;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
+        bp.fenced = reinterpret_cast<unsigned long long *>(t->d_stats + 65); bp.fence_slots = t->fence_slots;
         if (t->split_mesh) {
             bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
             bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
@@ -2278,8 +2291,10 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMalloc(&t->d_stamps, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
     HC(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
 #endif
-    HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 65));
-    HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 65));
+    HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 66));
+    HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 66));
+    t->fence_slots = (uint32_t)t->cap;
+    if (const char *e = getenv("PTX_DEBUG_FENCE_SLOTS")) t->fence_slots = (uint32_t)std::min<long long>(t->cap, std::max<long long>(1, atoll(e)));      // tests only
 #undef HC
     *out = t;
     return PTX_OK;
@@ -2318,7 +2333,7 @@ int ptx_reset_image(ptx_tracer *t) {
     if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipMemsetAsync(t->d_image, 0, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, t->stream));
-    HIPCHECK(hipMemsetAsync(t->d_stats, 0, sizeof(int64_t) * 65, t->stream));
+    HIPCHECK(hipMemsetAsync(t->d_stats, 0, sizeof(int64_t) * 66, t->stream));
     t->iterations = 0; t->loop_ms_total = 0.0; t->cache_valid = false;
     return PTX_OK;
 }
@@ -2553,12 +2568,13 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out) {
     if (!t || !out) return set_error(PTX_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
-    int64_t h[65];
+    int64_t h[66];
     HIPCHECK(hipMemcpy(h, t->d_stats, sizeof h, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->bounces = t->traceDepth;
     for (int b = 0; b < 64 && b < t->traceDepth; b++) out->rays_per_bounce[b] = h[b];
     out->rays_total = h[64];
+    out->fenced = h[65];
     for (int l = 1; l < MAX_LANES; l++) ahead_fold_time(t, l);
     out->loop_ms_total = t->loop_ms_total + (t->last_ahead_lane >= 0 ? 0.0 : ptx_last_loop_ms(t));
     out->iterations = t->iterations;

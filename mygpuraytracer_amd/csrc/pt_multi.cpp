@@ -273,6 +273,7 @@ int ptx_multi_get_stats(ptx_multi *m, ptx_stats *out) {
         out->bounces = s.bounces > out->bounces ? s.bounces : out->bounces;
         for (int b = 0; b < 64; b++) out->rays_per_bounce[b] += s.rays_per_bounce[b];
         out->rays_total += s.rays_total;
+        out->fenced += s.fenced;
         if (s.loop_ms_total > out->loop_ms_total) out->loop_ms_total = s.loop_ms_total;
         if (i == 0) out->iterations = s.iterations;
     }

@@ -14,9 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def usage():
-    if not shutil.which("hipcc"):
-        pytest.skip("hipcc is not on PATH: nothing to compile the kernels with")
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"), "resource-usage"], capture_output=True, text=True, timeout=900)
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if not hipcc:
+        # (the image of this project always has it: a skip here means the environment is not the one the library is built in)
+        pytest.skip("no hipcc on PATH or under /opt/rocm/bin: nothing to compile the kernels with -- register / occupancy guards NOT checked")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"), "resource-usage", "HIPCC=" + hipcc], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out, cur = {}, None
     for line in (r.stdout + r.stderr).splitlines():
@@ -46,12 +48,24 @@ def test_no_kernel_of_the_path_spills(usage):
 
 
 def test_specialised_bounce_kernels_fit_seven_waves(usage):
-    # only what the launch configuration relies on (enqueue_batch launches these as 7 workgroups per CU = 7 waves per SIMD; the
-    # split bounce's halves and k_mesh as what their launch bounds say) -- not the register counts of one compiler version
+    # what the launch configuration relies on (enqueue_batch launches the specialised unsplit kernels as 7 workgroups per CU = 7 waves
+    # per SIMD) ...
     for first in (0, 1):
         u = _bounce(usage, first, 0, 1)
-        assert u["waves"] >= 7, u
-        assert _bounce(usage, first, 1, 1)["waves"] >= 4
-        assert _bounce(usage, first, 2, 1)["waves"] >= 5
-    mesh = [v for k, v in usage.items() if "k_mesh" in k][0]
-    assert mesh["waves"] >= 5, mesh
+        assert u["waves"] >= 7 and u["vgprs"] <= 72, u
+
+
+def test_occupancy_headroom_does_not_regress(usage):
+    # ... and the occupancy the kernels HAVE beyond their launch bounds (launch bounds only force a floor: a change that costs pass 2
+    # two waves or k_mesh one would pass every parity test and the check above).  Floors = what DESIGN.md 5 quotes, one step below
+    # the values of the round-4 build (unsplit FAST 57-64 VGPRs / 8 waves, MODE 1 59-67 / 7, MODE 2 25-29 / 8, k_mesh 79-80 / 6).
+    for first in (0, 1):
+        for fast in (0, 1):
+            m1, m2 = _bounce(usage, first, 1, fast), _bounce(usage, first, 2, fast)
+            assert m1["waves"] >= 6 and m1["vgprs"] <= 80, (first, fast, m1)
+            assert m2["waves"] >= 7 and m2["vgprs"] <= 40, (first, fast, m2)
+        g = _bounce(usage, first, 0, 0)                  # the general kernel: 4 waves by its launch bounds, 128 registers
+        assert g["waves"] >= 4 and g["vgprs"] <= 128, g
+    for k, mesh in usage.items():
+        if "k_mesh" in k:
+            assert mesh["waves"] >= 6 and mesh["vgprs"] <= 84, (k, mesh)

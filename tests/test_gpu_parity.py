@@ -35,6 +35,52 @@ def O(oracle_lib):
     oracle_lib.set_libm(0)
 
 
+@pytest.fixture(autouse=True)
+def fences_stay_silent(gpu_product):
+    """Every index the kernels take from a table another launch wrote (mesh-search queue, parked ray's owner, sort index) is
+    range-checked before it becomes an address, and what a check stops is COUNTED (ptx_stats.fenced).  Every Tracer a test of this
+    module closes must have counted nothing: a corrupted queue shows as a number here, not only as a wrong pixel somewhere."""
+    pt = gpu_product
+    orig, seen = pt.Tracer.close, []
+
+    def close(self):
+        if getattr(self, "h", None) and not getattr(self, "expect_fenced", False):
+            try:
+                seen.append(self.stats()["fenced"])
+            except Exception:            # (a tracer left in an error state by a test of the error paths)
+                pass
+        orig(self)
+    pt.Tracer.close = close
+    yield
+    pt.Tracer.close = orig
+    assert not any(seen), "the kernels fenced %s indices: internal tables were corrupt" % seen
+
+
+def test_fences_count_what_they_stop(gpu_product, monkeypatch):
+    """The counter itself: with the fence limit lowered to one tile (PTX_DEBUG_FENCE_SLOTS = 256, tests only) every queue entry,
+    owner and sort-index entry beyond slot 255 is stopped -- skipped or clamped, so nothing is read or written out of range --
+    and counted.  Without the knob the same run counts 0."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship.txt"), res=(96, 54), depth=6)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s) as T:
+        T.render(1, 3)
+        assert T.stats()["fenced"] == 0
+        T.reset_image()
+        T.synchronize()
+        assert T.stats()["fenced"] == 0
+    monkeypatch.setenv("PTX_DEBUG_FENCE_SLOTS", "256")
+    for opt in ({}, dict(no_mesh_split=1)):
+        with pt.Tracer(s, **opt) as T:
+            T.expect_fenced = True
+            T.render(1, 3)
+            n = T.stats()["fenced"]
+            assert n > 0, opt
+            T.reset_image()                 # the counter is part of what reset clears
+            T.synchronize()
+            assert T.stats()["fenced"] == 0
+
+
 def test_device_libm_bit_identical(gpu_product, O):
     s, T = make_pair(gpu_product, O, "sphere.txt", (16, 16), 2)
     rng = np.random.default_rng(1)

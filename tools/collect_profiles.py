@@ -9,7 +9,8 @@ in KiB and reads half of the bytes on gfx950, MI355X_MICROARCH.md "HBM").
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_bounce<false": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh", "k_finish": "k_finish"}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profile_meta import kernel_label, source_sha16, how_of
 
 
 def main(tag, d_stats, d_fetch, d_write):
@@ -26,12 +27,12 @@ def main(tag, d_stats, d_fetch, d_write):
         shutil.copy(f, os.path.join(out, "%s_pmc_%s_size.csv" % (tag, kind)))
         a = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            for k, v in NAMES.items():
-                if k in r["Kernel_Name"]:
-                    a[v].append(float(r["Counter_Value"]))
+            lab = kernel_label(r["Kernel_Name"])
+            if lab:
+                a[lab].append(float(r["Counter_Value"]))
         acc[kind] = a
     res, detail = {}, {}
-    for k in NAMES.values():
+    for k in sorted(set(acc["fetch"]) | set(acc["write"])):
         f, w = acc["fetch"].get(k), acc["write"].get(k)
         if not f or not w:
             continue
@@ -48,10 +49,13 @@ def main(tag, d_stats, d_fetch, d_write):
             res["_units_per_launch"] = {line["roofline"]["kernel"]: line["roofline"]["units_per_launch"]}
         except Exception:
             pass
-    res["_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
-                   "--no-cpu-baseline --no-extra-legs; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
+    # what was profiled, as the profiling script itself recorded it next to its outputs (profile_round.sh / profile_c5.sh write
+    # <dir>_how.txt: the command after `--`, what a launch covers); never a fixed text -- round 2 and round 3 both shipped a C5
+    # traffic file that described the C4 command
+    res["_how"] = how_of(d_fetch) + ("; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
                    "FETCH_SIZE correction (checked in round 1 on the then k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
-                   "checked on torch's 24.9 MB fill = 24300 KiB). A launch covers 12 iterations (the default batch at 1080p).")
+                   "checked on torch's 24.9 MB fill = 24300 KiB).")
+    res["_source_sha16"] = source_sha16()      # of the kernel sources this was collected with (bench.py warns when they have changed since)
     json.dump(res, open(os.path.join(out, "traffic_%s.json" % tag), "w"), indent=1)
     if "c5" not in tag:                                # what bench.py reads
         json.dump(res, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)

@@ -6,8 +6,8 @@ per launch plus a few derived figures (VALU lane utilisation, share of wave time
 """
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_bounce<false": "k_bounce", "k_bounceILb0": "k_bounce", "k_bounce<true": "k_bounce<first>", "k_bounceILb1": "k_bounce<first>",
-         "k_move": "k_move", "k_gather": "k_gather", "k_mesh": "k_mesh", "k_finish": "k_finish"}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profile_meta import kernel_label, source_sha16, how_of
 
 
 def main(tag):
@@ -15,10 +15,9 @@ def main(tag):
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_?" % tag))):
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                for k, v in NAMES.items():
-                    if k in r["Kernel_Name"]:
-                        acc[v][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                        break
+                lab = kernel_label(r["Kernel_Name"])
+                if lab:
+                    acc[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, cs in acc.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -45,9 +44,9 @@ def main(tag):
         out["_units_per_launch"] = {line["roofline"]["kernel"]: line["roofline"]["units_per_launch"]}
     except Exception:
         pass
-    out["_how"] = ("rocprofv3 --pmc <8 counters> per pass (tools/pmc_sq.sh), no tracing, -- python3 bench.py --lanes 1 --steps 24 --warmup 12 "
-                   "--no-cpu-baseline --no-extra-legs; means per launch (a k_bounce launch = 12 iterations of one bounce). SQ_WAVE_CYCLES / SQ_WAIT_* / "
+    out["_how"] = how_of(os.path.join(ROOT, "gpurun_out", "pmc_%s" % tag)) + ("; means per launch. SQ_WAVE_CYCLES / SQ_WAIT_* / "
                    "SQ_ACTIVE_INST_* count quad-cycles summed over waves.")
+    out["_source_sha16"] = source_sha16()      # of the kernel sources this was collected with (bench.py warns when they have changed since)
     p = os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)
     json.dump(out, open(p, "w"), indent=1, sort_keys=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", "sq_latest.json"), "w"), indent=1, sort_keys=True)      # what bench.py reads

@@ -6,19 +6,17 @@ and the derived figures (VALU lane utilisation, VALU wave-instructions per launc
 """
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = [("k_bounceILb1ELi1", "pass1<first>"), ("k_bounceILb0ELi1", "pass1"), ("k_bounceILb1ELi2", "pass2<first>"), ("k_bounceILb0ELi2", "pass2"),
-         ("k_bounce<true, 1", "pass1<first>"), ("k_bounce<false, 1", "pass1"), ("k_bounce<true, 2", "pass2<first>"), ("k_bounce<false, 2", "pass2"),
-         ("k_meshILb1", "k_mesh<first>"), ("k_meshILb0", "k_mesh"), ("k_mesh<true", "k_mesh<first>"), ("k_mesh<false", "k_mesh"), ("k_gather", "k_gather")]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from profile_meta import kernel_label, source_sha16, how_of
 
 
 def main(tag):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_c5_%s_a" % tag, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            for k, v in NAMES:
-                if k in r["Kernel_Name"]:
-                    acc[v][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    break
+            lab = kernel_label(r["Kernel_Name"])
+            if lab:
+                acc[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, cs in acc.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -35,9 +33,8 @@ def main(tag):
                     d["share_of_wave_cycles_" + c] = g(c) / g("SQ_WAVE_CYCLES")
         m["_derived"] = d
         out[k] = m
-    out["_how"] = ("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU "
-                   "SQ_THREAD_CYCLES_VALU (tools/pmc_c5.sh, no tracing) -- python3 tools/gpu_c5_profile.py (cornellSpaceship20k.txt 3840x2160 depth 8 "
-                   "DoF, 16 iterations, lanes=1); means per launch.")
+    out["_how"] = how_of(os.path.join(ROOT, "gpurun_out", "pmc_c5_%s" % tag)) + "; means per launch."
+    out["_source_sha16"] = source_sha16()
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_c5_sq_counters.json" % tag), "w"), indent=1, sort_keys=True)
     for k, m in sorted(out.items()):
         if not k.startswith("_"):

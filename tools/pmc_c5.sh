@@ -8,5 +8,6 @@ cd /tmp && export TMPDIR=/tmp
 export C5_ITERS=16
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU"
 rm -rf $R/gpurun_out/pmc_c5_${TAG}_a
+echo "rocprofv3 --pmc $A (tools/pmc_c5.sh, no tracing) -- python3 tools/gpu_c5_profile.py: cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, $C5_ITERS iterations, lanes = 1; a launch covers the iterations of one launch set at 4K (batch = 5)" > $R/gpurun_out/pmc_c5_${TAG}_how.txt
 rocprofv3 --pmc $A --output-format csv -d $R/gpurun_out/pmc_c5_${TAG}_a -- python3 $R/tools/gpu_c5_profile.py > $R/gpurun_out/pmc_c5_${TAG}_a.log 2>&1
 echo "pass a done"
