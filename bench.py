@@ -11,7 +11,10 @@ bounces (the reference's own unit; about 5.37 M per step).  Inputs are resident 
            bench.py --gpus N --steps K --warmup W      # N ranks: interleaved row tiles + one RCCL reduce per run
 
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" (dominant kernel, algorithmic bytes / measured launch time)
-and "cpu_baseline" (the oracle, single thread, on this host), see DESIGN.md "Measurement".
+and "cpu_baseline" (the oracle, single thread, on this host), see DESIGN.md "Measurement".  With N > 1 the same line also carries,
+all OUTSIDE the timed region: "long_run" (200 steps of the same tile split: the regime where eight GPUs pay), "exchange_alt_ms"
+(the gather and the reduce spelling of the one exchange, each timed alone on the same buffers) and "c5" (BASELINE configs[4]: the
+3840x2160 textured-mesh scene traced as N row-tile ranks with its exchange).
 """
 import argparse
 import json
@@ -326,18 +329,19 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
-    def reduce_frame(img):
+    def reduce_frame(img, res=RES, how=None):
         """One reduce(SUM) of the accumulation buffer to rank 0: RCCL on the device buffer, or (gloo rehearsal) via host.
         --exchange gather: the owned rows only (pixel tiles; iteration sharding needs the sum)."""
-        if args.exchange == "gather" and not (world > 1 and args.shard == "iterations"):
-            multigpu.assemble_tiles(img, RES[0], RES[1], multigpu.TILE_ROWS, dst=0, via_host=args.backend != "nccl")
+        how = how or args.exchange
+        if how == "gather" and not (world > 1 and args.shard == "iterations"):
+            multigpu.assemble_tiles(img, res[0], res[1], multigpu.TILE_ROWS, dst=0, via_host=args.backend != "nccl")
         elif args.backend == "nccl":
-            dist.reduce(img[:RES[0] * RES[1] * 3], dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(img[:res[0] * res[1] * 3], dst=0, op=dist.ReduceOp.SUM)
         else:
-            h = img[:RES[0] * RES[1] * 3].cpu()
+            h = img[:res[0] * res[1] * 3].cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
-                img[:RES[0] * RES[1] * 3].copy_(h)
+                img[:res[0] * res[1] * 3].copy_(h)
 
     def all_reduce_scalar(value, dtype, op):
         tt = torch.tensor([value], dtype=dtype, device=device if args.backend == "nccl" else "cpu")
@@ -404,6 +408,79 @@ def main():
         dt = float(all_reduce_scalar(dt, torch.float64, dist.ReduceOp.MAX))
         rays = int(all_reduce_scalar(rays, torch.int64, dist.ReduceOp.SUM))
 
+    # ---- N > 1 only, OUTSIDE the timed region, same JSON line: what a single short scaling run cannot say by itself -------------
+    multi = None
+    if dist_on and not by_iter:
+        def timed_tile_run(tracer, img, res, first, count, how=None):
+            """`count` steps of this rank's tile + the exchange, bracketed like the timed region; max over ranks."""
+            r0 = tracer.stats()["rays_total"]
+            barrier()
+            a = time.perf_counter()
+            tracer.render(first, count)
+            tracer.synchronize()
+            b = time.perf_counter() - a
+            reduce_frame(img, res, how)
+            barrier()
+            c = time.perf_counter() - a
+            n = tracer.stats()["rays_total"] - r0
+            return (float(all_reduce_scalar(c, torch.float64, dist.ReduceOp.MAX)), float(all_reduce_scalar(b, torch.float64, dist.ReduceOp.MAX)),
+                    int(all_reduce_scalar(n, torch.int64, dist.ReduceOp.SUM)))
+
+        def exchange_alone(img, res, how, reps=5):
+            """the exchange by itself on the buffers of the run (median of `reps`; max over ranks): barrier, exchange, barrier"""
+            ts = []
+            for _ in range(reps + 1):
+                barrier()
+                a = time.perf_counter()
+                reduce_frame(img, res, how)
+                barrier()
+                ts.append(time.perf_counter() - a)
+            return float(all_reduce_scalar(sorted(ts[1:])[len(ts[1:]) // 2], torch.float64, dist.ReduceOp.MAX)) * 1e3
+
+        multi = {}
+        # (a) the long run: 200 steps of the same split.  The driver's 20 steps are a 3.4-ms problem on one GPU -- every rank's eight
+        # dependent bounce launches per launch set are then latency, not throughput (DESIGN.md 7); this is the regime the tile split
+        # is for.  Speed-up against one GPU = the N = 1 line's long_run (printed there too) / this.
+        LONG = 200
+        lt, lr, lrays = timed_tile_run(T, image, RES, 20_000_000, LONG)
+        multi["long_run"] = dict(steps=LONG, ms_per_step=lt / LONG * 1e3, value=lrays / lt / 1e6, unit="Mrays/s", slowest_rank_render_ms=lr * 1e3,
+                                 exchange_and_barrier_ms=(lt - lr) * 1e3, exchange=args.exchange)
+        # (b) both spellings of the one exchange on the same buffers (frames are complete: the long run just ended), each alone
+        scratch = image.clone()
+        multi["exchange_alt_ms"] = dict(gather=exchange_alone(scratch, RES, "gather"), reduce=exchange_alone(scratch, RES, "reduce"),
+                                        timed_with=args.exchange, frame_MB=RES[0] * RES[1] * 12 / 1e6, backend=args.backend,
+                                        what="barrier + exchange + barrier, median of 5, max over ranks; gather = every rank sends the 1/N of the "
+                                             "frame it owns to rank 0, reduce = RCCL reduce(SUM) of the zero-padded full frames (north_star's spelling): same frame bit for bit")
+        del scratch
+        # (c) BASELINE configs[4] as it is named: the 3840x2160 textured-mesh scene with depth of field on N ranks, its exchange included
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from conftest import ensure_standin_assets
+            if rank == 0:
+                ensure_standin_assets()
+            barrier()
+            C5RES, C5STEPS = (3840, 2160), 24
+            s5 = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=C5RES, depth=8)
+            s5.apply_runcuda_camera()
+            img5 = multigpu.frame_buffer(C5RES[0], C5RES[1], world, device)
+            torch.cuda.current_stream(device).synchronize()
+            kw5 = dict(device=dev_index, lanes=args.lanes, depth_of_field=1)
+            if world > 1:
+                kw5.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
+            with pt.Tracer(s5, external_image_ptr=img5.data_ptr(), **kw5) as T5:
+                T5.render(1, 12)
+                T5.synchronize()
+                reduce_frame(img5.clone(), C5RES)
+                ct, cr, crays = timed_tile_run(T5, img5, C5RES, 100, C5STEPS)
+                multi["c5"] = dict(ms_per_iteration=ct / C5STEPS * 1e3, steps=C5STEPS, rays_per_iteration=crays / C5STEPS, Mrays_per_s=crays / ct / 1e6,
+                                   slowest_rank_render_ms=cr * 1e3, exchange_and_barrier_ms=(ct - cr) * 1e3, exchange=args.exchange,
+                                   frame_MB=C5RES[0] * C5RES[1] * 12 / 1e6, fenced=T5.stats()["fenced"],
+                                   workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, %d row-tile ranks + 1 %s/run "
+                                            "(BASELINE configs[4] / C5; speed-up = the N = 1 line's c5_ms_per_iteration / this)" % (world, args.exchange))
+            del img5
+        except Exception as e:
+            multi["c5"] = dict(error=str(e)[:300])
+
     # roofline leg: the same K steps again with hipEvents around every launch (on the tracer's stream)
     T.set_kernel_timing(True)
     render_steps(args.warmup + args.steps + 1, args.steps)
@@ -457,10 +534,33 @@ def main():
                                              sq.get("_how", "tools/pmc_sq.sh"), "; scaled by rays per launch" if ref_units else ""))
         except Exception:
             valu_issue = None
+    # were the committed counter profiles taken with the kernel sources this run was built from?  (they are scaled into `traffic`,
+    # `valu_issue` and `bound` below: a stale profile would silently describe another kernel)
+    profiles_stale = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from profile_meta import source_sha16
+        now = source_sha16()
+        shas = {}
+        for nm in ("traffic_latest.json", "sq_latest.json"):
+            f = os.path.join(ROOT, "profiles", nm)
+            if os.path.exists(f):
+                shas[nm] = json.load(open(f)).get("_source_sha16")
+        profiles_stale = dict(kernel_sources_now=now, **{k: (v if v else "unrecorded (profile older than round 4)") for k, v in shas.items()},
+                              stale=any(v != now for v in shas.values()))
+        if rank == 0 and profiles_stale["stale"]:
+            print("bench.py: profiles/*_latest.json were collected with other kernel sources than this build's: traffic / valu_issue / bound "
+                  "describe THAT profile's kernels", file=sys.stderr)
+    except Exception as e:
+        profiles_stale = dict(error=str(e)[:120])
     loop_contract = CONTRACT_BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
     # One read tells what bounds the kernel: `bound` names it (vector-instruction issue -- valu_issue.frac of the issue peak), achieved /
     # frac / traffic are the HBM side of the same launches by this design's own bytes; the contract's record sizes are under contract_*.
-    roofline = dict(bound="valu" if valu_issue and valu_issue["frac"] > achieved / HBM_PEAK else "hbm", kernel=dominant,
+    roofline = dict(schema="r3+: achieved / frac / algorithmic_bytes_per_unit are THIS design's own layout bytes (~120 B per ray); rounds 1-2 put the "
+                           "contract's 196 B there, which now lives under contract_196B_frac -- BENCH_r02's frac compares with contract_196B_frac, not with frac",
+                    measured_in_this_run=["achieved", "frac", "avg_launch_us", "launches", "units_per_launch", "kernels_ms_per_step", "contract_*", "loop_ms_per_step"],
+                    from_committed_profiles=["traffic", "traffic_over_algorithmic", "physical_frac", "valu_issue", "bound"], profiles=profiles_stale,
+                    bound="valu" if valu_issue and valu_issue["frac"] > achieved / HBM_PEAK else "hbm", kernel=dominant,
                     achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
                     algorithmic_bytes_per_unit=own_bytes, traffic=traffic, traffic_source=traffic_source,
                     traffic_over_algorithmic=(traffic / (own_bytes * units)) if traffic and own_bytes else None,
@@ -477,6 +577,7 @@ def main():
     out = dict(metric="Mrays/s", value=rays / dt / 1e6, unit="Mrays/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
+               primary_rays_per_s=RES[0] * RES[1] * args.steps / dt,      # px * spp / s of the whole job (beside Mrays/s)
                config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
                            rccl_ranks=(dist.get_world_size() if dist_on else 1), backend=(args.backend if dist_on else None),
                            exchange=(None if not dist_on else "reduce" if by_iter else args.exchange),
@@ -486,6 +587,17 @@ def main():
                                         "%d ranks taking turns over the iterations of the full frame + 1 RCCL reduce/run" % world if by_iter else
                                         "%d row-tile ranks (%d-row interleaved blocks) + 1 RCCL %s/run" % (world, multigpu.TILE_ROWS, args.exchange))),
                roofline=roofline)
+    if multi:
+        out.update(multi)
+    elif rank == 0 and not args.no_extra_legs:
+        # one GPU: the same 200-step run the N-rank lines carry as "long_run", so that their speed-up has its denominator on record
+        r0 = T.stats()["rays_total"]
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        T.render(20_000_000, 200)
+        T.synchronize()
+        lt = time.perf_counter() - a
+        out["long_run"] = dict(steps=200, ms_per_step=lt / 200 * 1e3, value=(T.stats()["rays_total"] - r0) / lt / 1e6, unit="Mrays/s")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, args.cpu_iters)
     T.close()

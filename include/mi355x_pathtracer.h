@@ -227,7 +227,9 @@ int ptx_pin_host_buffer(void *p, size_t bytes);
 int ptx_unpin_host_buffer(void *p);
 
 /* Optional per-kernel device timing (hipEvents on the tracer's stream around every launch while on).
- * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh (split mesh search only: search + finishing of the parked rays), 3 = unused since round 3 (was k_move: the sort is inside k_bounce now; always 0).
+ * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh (split mesh search only: search + finishing of the
+ * parked rays), 3 = pass 2 of the split bounce (the ranking pass after k_mesh, first and later bounces; 0 for scenes without the split: kinds 0 / 1 are then the whole bounce,
+ * with the split they are its pass 1).
  * ptx_get_kernel_times returns the sums since it was last called and clears them. */
 int ptx_set_kernel_timing(ptx_tracer *t, int on);
 int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_by_kind[4]);

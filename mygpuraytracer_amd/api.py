@@ -22,6 +22,10 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmi355x_pathtracer.so")
+# A/B timing of variant builds (tools/ab_*.sh): PTX_AB_LIBRARY names another build of the SAME library to load instead, so that the
+# scripts no longer overwrite the in-tree product (an interrupted run used to leave a variant in its place).  Development only.
+if os.environ.get("PTX_AB_LIBRARY"):
+    LIB_PATH = os.path.abspath(os.environ["PTX_AB_LIBRARY"])
 
 PTX_OK = 0
 vp = C.c_void_p
@@ -596,7 +600,7 @@ class Tracer:
         ms = np.zeros(4, np.float64)
         n = np.zeros(4, np.int64)
         _check(self.lib.ptx_get_kernel_times(self.h, _ptr(ms), _ptr(n)), "ptx_get_kernel_times")
-        names = ("k_bounce<first>", "k_bounce", "k_mesh", "k_move")
+        names = ("k_bounce<first>", "k_bounce", "k_mesh", "k_bounce pass2")      # (split mesh search: the first two are then its pass 1)
         return {nm: (float(ms[k]), int(n[k])) for k, nm in enumerate(names)}
 
     def owned_pixels(self):

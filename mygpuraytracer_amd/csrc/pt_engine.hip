@@ -450,8 +450,8 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     TI_STAMP(7);
 }
 
-// What pass 1 of the split bounce (and k_finish, for the rays pass 1 parked) tells pass 2 about ray i: one word, lsrc[i] of the stage
-// until the tail overwrites it.  CAND = parked with mesh candidates in slot (bits 16-23) of its tile, k_finish will replace the
+// What pass 1 of the split bounce (and k_mesh, for the rays pass 1 parked) tells pass 2 about ray i: one word, lsrc[i] of the stage
+// until the tail overwrites it.  CAND = parked with mesh candidates in slot (bits 16-23) of its tile, k_mesh will replace the
 // word; otherwise the ray is finished -- alive / stored flags, its bin (bits 0-15) and, if stored, the slot its record lies in.
 constexpr int32_t K1_CAND = (int32_t)0x80000000u, K1_ALIVE = 0x40000000, K1_PEND = 0x20000000;
 
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (MODE == 1 && tid == 0) *ccnt = 0;           // (first touched after tileIntersect's barriers)
         if (MODE == 2) {                 // pass 1 left one word per ray; only the rays with mesh candidates were parked
             alive = false;
-            // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
+            // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_mesh)
             if (i < n_in) {
                 if (FIRST) k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
                 myslot = (k1 >> 16) & 0xff;
@@ -1513,7 +1513,7 @@ struct ptx_tracer {
     // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
     bool ktiming = false;
     std::vector<hipEvent_t> kev;                         // pairs (start, stop)
-    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh / k_finish, 3 unused (was k_move)
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh, 3 pass 2 of the split bounce (the ranking pass)
     size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;
@@ -1797,7 +1797,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             if (first) KT(2, hipLaunchKernelGGL(k_mesh<true>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
             else KT(2, hipLaunchKernelGGL(k_mesh<false>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
-            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
+            KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
@@ -1892,6 +1892,16 @@ int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
     t->iterations += 1;
     return PTX_OK;
 }
+
+// device scratch of the per-stage entry points: freed on every way out (a HIPCHECK that fails returns from the middle)
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    operator T *() const { return p; }
+};
 
 }  // namespace
 
@@ -2363,7 +2373,7 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
         const int kmin = (int)std::min<long long>(t->kmax, (t->split_min_paths + owned - 1) / owned);
         // ... and into TWO sets rather than three while two can hold the call: a one-shot of three sets starts its third
         // late (the host issues the sets one after the other) and makes all of them smaller -- 20 iterations as 10 + 10
-        // instead of 7 + 7 + 6: full frame equal, 1/2 tile -2 %, 1/4 and 1/8 tile -7 % (tools/gpu_short_tile_sweep.py)
+        // instead of 7 + 7 + 6: full frame equal, 1/2 tile -2 %, 1/4 and 1/8 tile -7 % (round 3's sweep; tools/gpu_tile_grid_sweep.py is its successor)
         int nsets = count <= 2 * t->kmax ? std::min(2, t->lanes) : t->lanes;
         if (t->dbg_nsets > 0) nsets = std::min(t->dbg_nsets, t->lanes);
         kb = std::min(t->kmax, std::max(kmin, (count + nsets - 1) / nsets));
@@ -2591,28 +2601,26 @@ int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float 
     KAT_PROLOGUE
     if (geom < 0 || geom >= t->ngeoms) return set_error(PTX_ERR_INVALID, "geom index out of range");
     if (n <= 0) return PTX_OK;
-    float *d_in = nullptr, *d_out = nullptr;
-    HIPCHECK(hipMalloc(&d_in, sizeof(float) * 6 * (size_t)n));
-    HIPCHECK(hipMalloc(&d_out, sizeof(float) * 10 * (size_t)n));
+    DevBuf<float> d_in; DevBuf<float> d_out;
+    HIPCHECK(hipMalloc(&d_in.p, sizeof(float) * 6 * (size_t)n));
+    HIPCHECK(hipMalloc(&d_out.p, sizeof(float) * 10 * (size_t)n));
     HIPCHECK(hipMemcpy(d_in, rays6, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_kat_geom, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), geom, n, d_in, d_out);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(out10, d_out, sizeof(float) * 10 * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(d_in); hipFree(d_out);
     return PTX_OK;
 }
 
 int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32) {
     KAT_PROLOGUE
     if (n <= 0) return PTX_OK;
-    HostPath *d_p = nullptr; HostIsect *d_i = nullptr;
-    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
-    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
+    DevBuf<HostPath> d_p; DevBuf<HostIsect> d_i;
+    HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i.p, sizeof(HostIsect) * (size_t)n));
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_kat_intersect, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), n, d_p, d_i);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(d_p); hipFree(d_i);
     return PTX_OK;
 }
 
@@ -2621,9 +2629,9 @@ int ptx_kat_tile_intersect(ptx_tracer *t, int n, const void *paths44, void *isec
     if (n <= 0) return PTX_OK;
     if (!t->cull || !t->tri_lds) return set_error(PTX_ERR_UNSUPPORTED, "this scene does not take the tile path (candidate masks / LDS tables are off)");
     if (split && !t->d_bvh_root) return set_error(PTX_ERR_UNSUPPORTED, "no mesh of this scene has a BVH: nothing for the split mesh search to do");
-    HostPath *d_p = nullptr; HostIsect *d_i = nullptr;
-    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
-    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
+    DevBuf<HostPath> d_p; DevBuf<HostIsect> d_i;
+    HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i.p, sizeof(HostIsect) * (size_t)n));
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
     // the scene as enqueue_batch hands it to k_bounce (tables staged; split: without the triangle tables) and as k_mesh gets it
     DScene sc = t->scene();
@@ -2632,43 +2640,48 @@ int ptx_kat_tile_intersect(ptx_tracer *t, int n, const void *paths44, void *isec
     DScene scg = t->scene();
     scg.bvh_stack = t->bvh_stack;
     const size_t lds = sizeof(int32_t) * (bounceLdsWords(sceneTableWords(sc.ntri_lds, t->nmats, t->ngeoms), 1) + (split ? (size_t)t->bvh_stack * TILE : 0));
+    {   // ptx_create sized k_bounce's LDS against the device (stepping the tables down where needed); this kernel adds the walks'
+        // stacks on top of the same layout, so it is checked here, where the caller can be told, not at the launch
+        int lim = 0;
+        HIPCHECK(hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, t->device));
+        if (lds > (size_t)lim)
+            return set_error(PTX_ERR_UNSUPPORTED, "ptx_kat_tile_intersect needs " + std::to_string(lds) + " bytes of LDS per workgroup (scene tables + " +
+                             std::to_string(t->bvh_stack) + " stack entries per lane), the device offers " + std::to_string(lim));
+    }
     const dim3 grid((unsigned)std::min(1024, (n + TILE - 1) / TILE));
     if (split) hipLaunchKernelGGL(k_kat_tile<true>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
     else hipLaunchKernelGGL(k_kat_tile<false>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(d_p); hipFree(d_i);
     return PTX_OK;
 }
 
 int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void *isects32, void *paths44) {
     KAT_PROLOGUE
     if (n <= 0) return PTX_OK;
-    HostPath *d_p = nullptr; HostIsect *d_i = nullptr; int32_t *d_x = nullptr;
-    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
-    HIPCHECK(hipMalloc(&d_i, sizeof(HostIsect) * (size_t)n));
-    HIPCHECK(hipMalloc(&d_x, sizeof(int32_t) * (size_t)n));
+    DevBuf<HostPath> d_p; DevBuf<HostIsect> d_i; DevBuf<int32_t> d_x;
+    HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_i.p, sizeof(HostIsect) * (size_t)n));
+    HIPCHECK(hipMalloc(&d_x.p, sizeof(int32_t) * (size_t)n));
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_i, isects32, sizeof(HostIsect) * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_x, idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_kat_shade, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), iter, n, d_x, d_i, d_p);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(d_p); hipFree(d_i); hipFree(d_x);
     return PTX_OK;
 }
 
 int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44) {
     KAT_PROLOGUE
     int n = t->cam.resx * t->cam.resy;
-    HostPath *d_p = nullptr;
-    HIPCHECK(hipMalloc(&d_p, sizeof(HostPath) * (size_t)n));
+    DevBuf<HostPath> d_p;
+    HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
     hipLaunchKernelGGL(k_kat_generate, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->cam, iter, t->traceDepth,
                        t->opt.antialiasing, t->opt.depth_of_field, d_p);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(d_p);
     return PTX_OK;
 }
 
@@ -2676,10 +2689,10 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
                  double *pow5_out, const float *powf_xy, float *powf_out) {
     KAT_PROLOGUE
     if (n <= 0) return PTX_OK;
-    float *dx, *ds, *dc, *dxy, *dpo; double *dpw, *dp5;
-    HIPCHECK(hipMalloc(&dx, 4 * (size_t)n)); HIPCHECK(hipMalloc(&ds, 4 * (size_t)n)); HIPCHECK(hipMalloc(&dc, 4 * (size_t)n));
-    HIPCHECK(hipMalloc(&dxy, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dpo, 4 * (size_t)n));
-    HIPCHECK(hipMalloc(&dpw, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dp5, 8 * (size_t)n));
+    DevBuf<float> dx, ds, dc, dxy, dpo; DevBuf<double> dpw, dp5;
+    HIPCHECK(hipMalloc(&dx.p, 4 * (size_t)n)); HIPCHECK(hipMalloc(&ds.p, 4 * (size_t)n)); HIPCHECK(hipMalloc(&dc.p, 4 * (size_t)n));
+    HIPCHECK(hipMalloc(&dxy.p, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dpo.p, 4 * (size_t)n));
+    HIPCHECK(hipMalloc(&dpw.p, 8 * (size_t)n)); HIPCHECK(hipMalloc(&dp5.p, 8 * (size_t)n));
     HIPCHECK(hipMemcpy(dx, x, 4 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dpw, pw_in, 8 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dxy, powf_xy, 8 * (size_t)n, hipMemcpyHostToDevice));
@@ -2689,7 +2702,6 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
     HIPCHECK(hipMemcpy(cos_out, dc, 4 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(pow5_out, dp5, 8 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(powf_out, dpo, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(ds); hipFree(dc); hipFree(dxy); hipFree(dpo); hipFree(dpw); hipFree(dp5);
     return PTX_OK;
 }
 
