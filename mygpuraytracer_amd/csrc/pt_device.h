@@ -621,95 +621,125 @@ PT_HD float bvhNearestOrdered(const BvhQuad *__restrict__ nodes, const float *__
 // slot, bit 31 set = leaf (count << 24 | first triangle in the low 24 bits), else the entry's own wide node.  The entries of a node
 // that are hit -- leaves and inner nodes alike -- are visited nearest first, the others pushed farthest first.  `nodes` / `root`:
 // the binary tree, for the root box and the slack.
-PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__restrict__ wide, const float *__restrict__ tris, int root,
-                           int wroot, vec3 o, vec3 d, int &face, float &b0o, float &b1o, int32_t *stack, int stride, int *visited = nullptr) {
+// The walk is written as a state (WideWalk) and two steps -- wideNodeStep: one four-wide node; wideLeafStep: the triangles of the leaf
+// in hand, all of them or one -- so that the SAME code serves two schedules: bvhNearestWide below (one ray to its end: "while-while")
+// and k_mesh's refilling waves (pt_engine.hip), where a lane whose walk has ended takes the next parked ray instead of idling.
+constexpr int32_t WIDE_DONE = (int32_t)0x80000000;           // (a leaf reference with count 0: no leaf is encoded like this)
+struct WideWalk {
+    vec3 o, d;                                               // object-space ray (d normalised the way meshTestCore does)
+    float ix, iy, iz, enx, eny, enz, efx, efy, efz;          // 1/d, and the slab origin terms with the slack inside (see wideNodeStep)
+    float tmin; int32_t face; float b0, b1;                  // best so far: distance, face (index inside the geom), its barycentrics
+    int32_t sp, n;                                           // stack entries in use; what is in hand: >= 0 a wide node, WIDE_DONE, else a leaf reference
+};
+// Sets the walk up at the root; n = WIDE_DONE when the ray misses the root box.
+PT_HD void wideStart(WideWalk &w, const BvhQuad *__restrict__ nodes, int root, int wroot, vec3 o, vec3 d, int *visited = nullptr) {
     const RaySlab rs = makeRaySlab(o, d, bvhSlack(nodes[2 * root], nodes[2 * root + 1], o));
-    float tmin = 3.402823466e+38f;
-    face = -1; b0o = 0.f; b1o = 0.f;
-    {
-        float tn;
-        if (visited) ++*visited;
-        if (!slabEntry(nodes[2 * root], nodes[2 * root + 1], rs, tmin, tn)) return tmin;
-    }
-    // Two loops in turn ("while-while"): the lanes of a wave first walk INNER nodes together -- four box tests, the entries that are
-    // hit sorted by entry distance, the nearest taken, the others pushed, leaves and inner entries alike -- until every lane holds a
-    // leaf or is done; then the lanes that hold a leaf test its triangles together and take their next entry from the stack.  The
-    // triangle code, an order of magnitude longer than what most lanes of a wave need at any one node, is thereby issued once per
-    // leaf a lane visits, not four times per node any lane of the wave visits (counters, 20 448 triangles: 23 % of the lanes active
-    // per vector instruction before).  A hit prunes through tmin as before: every box is tested against the best distance when its
-    // node is visited.
-    constexpr int32_t DONE = (int32_t)0x80000000;           // (a leaf reference with count 0: no leaf is encoded like this)
-    const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;       // (1/d is finite and not 0: makeRaySlab)
-    const float enx = -(rs.ox + rs.sx), eny = -(rs.oy + rs.sy), enz = -(rs.oz + rs.sz);
-    const float efx = rs.sx - rs.ox, efy = rs.sy - rs.oy, efz = rs.sz - rs.oz;
-    int sp = 0, n = wroot;
-    for (;;) {
-        while (n >= 0) {
-            const BvhWide4 *W = wide + (size_t)n * 4;
-            const BvhWide4 Q0 = W[0], Q1 = W[1], Q2 = W[2], Q3 = W[3];     // one 64-byte line
-            if (visited) *visited += 4;
-            const float ox = __int_as_float_hd(Q0.a), oy = __int_as_float_hd(Q0.b), oz = __int_as_float_hd(Q0.c);
-            const float sx = __int_as_float_hd(Q0.d), sy = __int_as_float_hd(Q1.a), sz = __int_as_float_hd(Q1.b);
-            const int r0 = Q1.c, r1 = Q1.d, r2 = Q2.a, r3 = Q2.b;
-            const uint32_t lx = (uint32_t)Q2.c, ly = (uint32_t)Q2.d, lz = (uint32_t)Q3.a, hx = (uint32_t)Q3.b, hy = (uint32_t)Q3.c, hz = (uint32_t)Q3.d;
-            const float none = __builtin_inff();
-            float t0 = none, t1 = none, t2 = none, t3 = none;
-            int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
-            // which of an entry's two planes per axis the ray meets first is the same for all four entries: the word that holds the
-            // NEAR planes' grid coordinates is picked once per node (by the sign of 1/d), and the slack is inside the origin terms
-            // (en = -(o/d + slack/|d|), ef = -(o/d - slack/|d|)): a box is 12 conversions, 12 fused multiply-adds, a max3, a min3 and
-            // three compares -- slabEntry's planes, interval and three reasons to skip, without its minima / maxima per axis.
-            const uint32_t nxw = negx ? hx : lx, fxw = negx ? lx : hx, nyw = negy ? hy : ly, fyw = negy ? ly : hy, nzw = negz ? hz : lz, fzw = negz ? lz : hz;
-            const float tcut = tmin * 1.0001f;
+    w.o = o; w.d = d;
+    w.tmin = 3.402823466e+38f; w.face = -1; w.b0 = 0.f; w.b1 = 0.f;
+    w.ix = rs.ix; w.iy = rs.iy; w.iz = rs.iz;
+    w.enx = -(rs.ox + rs.sx); w.eny = -(rs.oy + rs.sy); w.enz = -(rs.oz + rs.sz);
+    w.efx = rs.sx - rs.ox; w.efy = rs.sy - rs.oy; w.efz = rs.sz - rs.oz;
+    w.sp = 0;
+    float tn;
+    if (visited) ++*visited;
+    w.n = slabEntry(nodes[2 * root], nodes[2 * root + 1], rs, w.tmin, tn) ? wroot : WIDE_DONE;
+}
+// One wide node (w.n >= 0): four box tests, the entries that are hit sorted by entry distance, the nearest taken in hand, the others
+// pushed farthest first -- leaves and inner entries alike.  Afterwards w.n is an inner node, a leaf reference or WIDE_DONE.
+PT_HD void wideNodeStep(WideWalk &w, const BvhWide4 *__restrict__ wide, int32_t *stack, int stride, int *visited = nullptr, int *trace = nullptr) {
+    const BvhWide4 *W = wide + (size_t)w.n * 4;
+    const BvhWide4 Q0 = W[0], Q1 = W[1], Q2 = W[2], Q3 = W[3];     // one 64-byte line
+    if (visited) *visited += 4;
+    if (trace) trace[++trace[0]] = 0;
+    const float ox = __int_as_float_hd(Q0.a), oy = __int_as_float_hd(Q0.b), oz = __int_as_float_hd(Q0.c);
+    const float sx = __int_as_float_hd(Q0.d), sy = __int_as_float_hd(Q1.a), sz = __int_as_float_hd(Q1.b);
+    const int r0 = Q1.c, r1 = Q1.d, r2 = Q2.a, r3 = Q2.b;
+    const uint32_t lx = (uint32_t)Q2.c, ly = (uint32_t)Q2.d, lz = (uint32_t)Q3.a, hx = (uint32_t)Q3.b, hy = (uint32_t)Q3.c, hz = (uint32_t)Q3.d;
+    const float none = __builtin_inff();
+    float t0 = none, t1 = none, t2 = none, t3 = none;
+    int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+    // which of an entry's two planes per axis the ray meets first is the same for all four entries: the word that holds the
+    // NEAR planes' grid coordinates is picked once per node (by the sign of 1/d, which is finite and not 0: makeRaySlab), and the slack
+    // is inside the origin terms (en = -(o/d + slack/|d|), ef = -(o/d - slack/|d|)): a box is 12 conversions, 12 fused multiply-adds,
+    // a max3, a min3 and three compares -- slabEntry's planes, interval and three reasons to skip, without its minima / maxima per axis.
+    const bool negx = w.ix < 0.0f, negy = w.iy < 0.0f, negz = w.iz < 0.0f;
+    const uint32_t nxw = negx ? hx : lx, fxw = negx ? lx : hx, nyw = negy ? hy : ly, fyw = negy ? ly : hy, nzw = negz ? hz : lz, fzw = negz ? lz : hz;
+    const float tcut = w.tmin * 1.0001f;
 #define PT_WIDE_ENTRY(K, REF, TK, CK)                                                                                          \
-            if (REF != -1) {                                                                                                   \
-                const float ax = __builtin_fmaf((float)((nxw >> (8 * K)) & 255u), sx, ox), bx = __builtin_fmaf((float)((fxw >> (8 * K)) & 255u), sx, ox); \
-                const float ay = __builtin_fmaf((float)((nyw >> (8 * K)) & 255u), sy, oy), by = __builtin_fmaf((float)((fyw >> (8 * K)) & 255u), sy, oy); \
-                const float az = __builtin_fmaf((float)((nzw >> (8 * K)) & 255u), sz, oz), bz = __builtin_fmaf((float)((fzw >> (8 * K)) & 255u), sz, oz); \
-                const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ax, rs.ix, enx), __builtin_fmaf(ay, rs.iy, eny)), __builtin_fmaf(az, rs.iz, enz)); \
-                const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bx, rs.ix, efx), __builtin_fmaf(by, rs.iy, efy)), __builtin_fmaf(bz, rs.iz, efz)); \
-                if (!((tf < tn) || (tf < 0.0f) || (tn > tcut))) { TK = tn; CK = REF; }                                         \
-            }
-            PT_WIDE_ENTRY(0, r0, t0, c0)
-            PT_WIDE_ENTRY(1, r1, t1, c1)
-            PT_WIDE_ENTRY(2, r2, t2, c2)
-            PT_WIDE_ENTRY(3, r3, t3, c3)
+    if (REF != -1) {                                                                                                   \
+        const float ax = __builtin_fmaf((float)((nxw >> (8 * K)) & 255u), sx, ox), bx = __builtin_fmaf((float)((fxw >> (8 * K)) & 255u), sx, ox); \
+        const float ay = __builtin_fmaf((float)((nyw >> (8 * K)) & 255u), sy, oy), by = __builtin_fmaf((float)((fyw >> (8 * K)) & 255u), sy, oy); \
+        const float az = __builtin_fmaf((float)((nzw >> (8 * K)) & 255u), sz, oz), bz = __builtin_fmaf((float)((fzw >> (8 * K)) & 255u), sz, oz); \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(ax, w.ix, w.enx), __builtin_fmaf(ay, w.iy, w.eny)), __builtin_fmaf(az, w.iz, w.enz)); \
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bx, w.ix, w.efx), __builtin_fmaf(by, w.iy, w.efy)), __builtin_fmaf(bz, w.iz, w.efz)); \
+        if (!((tf < tn) || (tf < 0.0f) || (tn > tcut))) { TK = tn; CK = REF; }                                         \
+    }
+    PT_WIDE_ENTRY(0, r0, t0, c0)
+    PT_WIDE_ENTRY(1, r1, t1, c1)
+    PT_WIDE_ENTRY(2, r2, t2, c2)
+    PT_WIDE_ENTRY(3, r3, t3, c3)
 #undef PT_WIDE_ENTRY
-            // the entries that were hit, by entry distance: a five-exchange network on (distance, reference) pairs in registers (static
-            // indices only); the slots that were not hit carry +inf and sink to the end.  (An entry whose distance is a NaN -- "visit" by
-            // slabEntry's rule -- may stay behind an empty slot: every slot is looked at below, so it is visited all the same.)
+    // the entries that were hit, by entry distance: a five-exchange network on (distance, reference) pairs in registers (static
+    // indices only); the slots that were not hit carry +inf and sink to the end.  (An entry whose distance is a NaN -- "visit" by
+    // slabEntry's rule -- may stay behind an empty slot: every slot is looked at below, so it is visited all the same.)
 #define PT_CX(ta, ca, tb, cb) do { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; const int cc_ = sw_ ? cb : ca; \
                                    tb = sw_ ? ta : tb; cb = sw_ ? ca : cb; ta = tt_; ca = cc_; } while (0)
-            PT_CX(t0, c0, t1, c1); PT_CX(t2, c2, t3, c3); PT_CX(t0, c0, t2, c2); PT_CX(t1, c1, t3, c3); PT_CX(t1, c1, t2, c2);
+    PT_CX(t0, c0, t1, c1); PT_CX(t2, c2, t3, c3); PT_CX(t0, c0, t2, c2); PT_CX(t1, c1, t3, c3); PT_CX(t1, c1, t2, c2);
 #undef PT_CX
-            // nearest in hand, the others onto the stack farthest first
-            if (c3 != -1) { stack[sp * stride] = c3; sp++; }
-            if (c2 != -1) { stack[sp * stride] = c2; sp++; }
-            if (c1 != -1) { stack[sp * stride] = c1; sp++; }
-            n = c0;
-            if (n == -1) n = sp ? stack[--sp * stride] : DONE;
-        }
-        if (n == DONE) return tmin;
-        {   // a leaf: its triangles
-            const int count = (int)(((uint32_t)n >> 24) & 0x7fu), first = n & 0x00ffffff;
-            if (visited) *visited += count << 16;         // (triangle tests, counted apart from the node visits in the low half)
-            for (int j = 0; j < count; j++) {
-                const float *T = tris + (size_t)(first + j) * BVH_TRI;
-                const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);
-                const vec3 e1 = sub(p1, v0), e2 = sub(p2, v0);
-                float b0, b1;
-                if (rayTriangle(o, d, v0, e1, e2, b0, b1)) {
-                    const float w = 1 - b0 - b1;
-                    const vec3 p = add(add(scale(v0, w), scale(p1, b0)), scale(p2, b1));
-                    const float t = length(sub(o, p));
-                    int f;
-                    __builtin_memcpy(&f, &T[9], 4);
-                    if (t < tmin || (t == tmin && f < face)) { tmin = t; face = f; b0o = b0; b1o = b1; }
-                }
-            }
-            n = sp ? stack[--sp * stride] : DONE;
+    // nearest in hand, the others onto the stack farthest first
+    int sp = w.sp;
+    if (c3 != -1) { stack[sp * stride] = c3; sp++; }
+    if (c2 != -1) { stack[sp * stride] = c2; sp++; }
+    if (c1 != -1) { stack[sp * stride] = c1; sp++; }
+    int n = c0;
+    if (n == -1) n = sp ? stack[--sp * stride] : WIDE_DONE;
+    w.sp = sp; w.n = n;
+}
+// The leaf in hand (w.n: bit 31, count << 24, first triangle): ALL its triangles (ONE = false), or the first of them, the rest staying
+// in hand as a shorter leaf (ONE = true: k_mesh's refilling waves, where a lane with a one-triangle leaf should not wait for its
+// neighbour's four).  The per-triangle arithmetic and the (distance, face index) minimum are meshTestCore's.
+template <bool ONE>
+PT_HD void wideLeafStep(WideWalk &w, const float *__restrict__ tris, int32_t *stack, int stride, int *visited = nullptr, int *trace = nullptr) {
+    const int count = (int)(((uint32_t)w.n >> 24) & 0x7fu), first = w.n & 0x00ffffff;
+    if (visited) *visited += (ONE ? 1 : count) << 16;       // (triangle tests, counted apart from the node visits in the low half)
+    if (trace) trace[++trace[0]] = ONE ? 1 : count;
+    const int todo = ONE ? 1 : count;
+    for (int j = 0; j < todo; j++) {
+        const float *T = tris + (size_t)(first + j) * BVH_TRI;
+        // (e1 = p1 - v0, e2 = p2 - v0: the subtractions the upload-time table holds, done here -- same IEEE results, one load less)
+        const vec3 v0 = V3(T[0], T[1], T[2]), p1 = V3(T[3], T[4], T[5]), p2 = V3(T[6], T[7], T[8]);
+        const vec3 e1 = sub(p1, v0), e2 = sub(p2, v0);
+        float b0, b1;
+        if (rayTriangle(w.o, w.d, v0, e1, e2, b0, b1)) {
+            const float wgt = 1 - b0 - b1;
+            const vec3 p = add(add(scale(v0, wgt), scale(p1, b0)), scale(p2, b1));
+            const float t = length(sub(w.o, p));
+            int f;
+            __builtin_memcpy(&f, &T[9], 4);
+            if (t < w.tmin || (t == w.tmin && f < w.face)) { w.tmin = t; w.face = f; w.b0 = b0; w.b1 = b1; }
         }
     }
+    if (ONE && count > 1) w.n = (int32_t)(0x80000000u | ((uint32_t)(count - 1) << 24) | (uint32_t)(first + 1));
+    else w.n = w.sp ? stack[--w.sp * stride] : WIDE_DONE;
+}
+
+PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__restrict__ wide, const float *__restrict__ tris, int root,
+                           int wroot, vec3 o, vec3 d, int &face, float &b0o, float &b1o, int32_t *stack, int stride, int *visited = nullptr,
+                           int *trace = nullptr) {      // trace (host experiments only, tools/mesh_walk_sim.cpp): trace[0] = n, then n steps: 0 = a node, k > 0 = a leaf of k triangles
+    // Two loops in turn ("while-while"): the lanes of a wave first walk INNER nodes together until every lane holds a leaf or is done;
+    // then the lanes that hold a leaf test its triangles together and take their next entry from the stack.  The triangle code, an
+    // order of magnitude longer than what most lanes of a wave need at any one node, is thereby issued once per leaf a lane visits, not
+    // four times per node any lane of the wave visits.  A hit prunes through tmin: every box is tested against the best distance when
+    // its node is visited.
+    WideWalk w;
+    wideStart(w, nodes, root, wroot, o, d, visited);
+    for (;;) {
+        while (w.n >= 0) wideNodeStep(w, wide, stack, stride, visited, trace);
+        if (w.n == WIDE_DONE) break;
+        wideLeafStep<false>(w, tris, stack, stride, visited, trace);
+    }
+    face = w.face; b0o = w.b0; b1o = w.b1;
+    return w.tmin;
 }
 
 // meshIntersectionTest up to the choice of the nearest face, src/intersections.h:207-233.  Returns the OBJECT-space

@@ -225,6 +225,7 @@ struct BounceParams {
     int32_t iter_stride;                   // iteration of segment s = iter + s * iter_stride (1; world size when ranks take turns)
     // split mesh search (MODE 1 / 2 of k_bounce, k_mesh in between): per-ray keys, the queue of parked rays (their stage slots)
     unsigned long long *keys; uint32_t *items; int32_t *item_count;
+    int32_t *item_cursor;                  // one int per segment, after the counts: where k_mesh's waves draw their next chunk of the queue
     size_t seg_keys, seg_items;            // per-segment strides of keys / items; item_count has one int per segment
     int32_t *tile_done;                    // split first bounce: [segment][tile] 1 = pass 1 finished the tile (no ray of it reaches a mesh's box)
     int32_t aa, dof, sort;
@@ -1129,19 +1130,136 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #endif
 }
 
-// Split mesh search, middle part: one lane per PARKED ray (round 3: per ray, not per (ray, mesh) pair, and the ray is finished here).
-// The ray is read from the slot pass 1 parked it in, every mesh whose box it reaches is searched (four-wide BVH walk, or the
-// plain loop for a mesh without a tree; tables in global memory) and the nearest of their keys and the key pass 1 left (cubes and
-// spheres) is the ray's hit -- the same keys and the same minimum as in tileIntersect, so the same winner.  When every lane of the
-// wave has ended its walk the wave FINISHES its rays together: hit decoded, terminal cases, the record completed in the slot the ray
-// was parked in if it goes on, and the one word pass 2 needs left in lsrc[owner].  Dense lanes that all do the same thing: the
-// dependent face / texel loads of a textured mesh hit, which held a whole tile at a barrier when pass 2 did this, hide behind the
-// other waves.  (An earlier form of the round had a kernel of its own for the finishing, k_finish, and 64-bit atomic minima for rays
-// that reach two meshes' boxes: one launch and the atomics less.)
+// Split mesh search, middle part (round 4: refilling waves).  The queue holds one entry per PARKED ray (its stage slot); which
+// meshes' boxes the ray reaches travels with it as a bit per geom.  The search of one ray is a walk of unpredictable length -- 9 wide
+// nodes and 6 triangles on average on the 20 448-triangle stand-in, the longest of 64 consecutive rays 3-5 times that -- and rounds 2-3
+// gave every lane ONE ray: a wave then issues for its slowest lane, 19 % of the lanes active per vector instruction (round 3's
+// counters; tools/mesh_walk_sim.cpp reproduces 16 % on the CPU from the walks' step sequences).  Ordering the queue by direction
+// octant / entry cell so that neighbouring lanes walk alike buys 5-10 % (same simulator: the spread is in the LENGTHS, not in the
+// paths).  So a wave now keeps its lanes busy instead: it draws chunks of the queue (one global atomic per PT_MESH_CHUNK entries and
+// wave, on a per-segment cursor), every lane holds the walk state of one ray (WideWalk, pt_device.h), and the wave alternates
+//   * a NODE round  -- the lanes whose walk holds an inner node do one four-wide node step -- while at least PT_MESH_NMIN lanes do, or
+//                      no lane holds a leaf;
+//   * a LEAF round  -- the lanes that hold a leaf test ONE of its triangles;
+//   * a TURNOVER    -- once PT_MESH_REFILL lanes have nothing to walk (or nothing else is left to do): walks that ended fold their
+//                      key into the ray's (minimum of the meshes' keys and the key pass 1 left: cubes and spheres), rays with another
+//                      candidate mesh set up its walk, finished rays store their key, free lanes take the next queue entries.
+// Same steps on the same data per ray -- wideNodeStep / wideLeafStep are what bvhNearestWide runs -- so the same keys (every mesh test
+// green on either schedule); per 64 rays the simulator counts 7.0 k instead of 16.7 k instruction slots (with 220 per turnover and 25
+// per round of scheduling), 42 % of the lanes active.  The finishing of the rays (hit decode, terminal cases, record) is k_finish
+// again, one dense lane per queue entry: its code and registers do not ride along with the walks.
+// Exit: every wave ends when the cursor has passed the queue's end and none of its lanes holds a ray -- each round advances every lane
+// it runs, each turnover consumes queue entries or retires rays, so the loop ends for any queue content (bad entries are fenced).
+#ifndef PT_MESH_CHUNK
+#define PT_MESH_CHUNK 256     // queue entries a wave reserves per global atomic
+#endif
+#ifndef PT_MESH_REFILL
+#define PT_MESH_REFILL 16     // lanes without a walk that trigger a turnover
+#endif
+#ifndef PT_MESH_NMIN
+#define PT_MESH_NMIN 32       // lanes holding an inner node that make the next round a node round
+#endif
 template <bool FIRST>
 __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams p_in, int bvh_stack) {
     BounceParams p = p_in;
     p.sc.tri_lds = 0; p.sc.ntri_lds = 0; p.sc.bvh_stack = bvh_stack;      // (no LDS tables in this kernel; LDS = the walks' stacks)
+    const int seg = blockIdx.y;
+    const int n = p.item_count[seg];
+    const int lane = threadIdx.x & 63;
+    const PathSoA st = soa_offset(p.stage, p.seg_stage * seg);
+    const uint32_t *items = p.items + p.seg_items * seg;
+    unsigned long long *keys = p.keys + p.seg_keys * seg;
+    int32_t *cursor = p.item_cursor + seg;
+    const uint32_t slots = p.fence_slots;
+    const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
+    int32_t *stack = pt_lds + threadIdx.x;
+    constexpr int32_t IDLE = (int32_t)0x80000001;             // (no leaf reference looks like this either: count 0)
+    // per-lane state: the ray in hand (sa: its stage slot; < 0: none), the meshes still to search, the best key so far, the walk
+    int32_t sa = -1, g = 0;
+    uint32_t mask = 0;
+    unsigned long long key = KEY_NONE;
+    WideWalk w;
+    w.n = IDLE; w.sp = 0; w.tmin = 0.f; w.face = -1; w.b0 = w.b1 = 0.f;
+    w.o = w.d = V3(0.f, 0.f, 0.f); w.ix = w.iy = w.iz = w.enx = w.eny = w.enz = w.efx = w.efy = w.efz = 0.f;
+    int cur = 0, end = 0;                                    // (wave-uniform) the chunk of the queue this wave is drawing from
+    bool more = n > 0;                                       // (wave-uniform) the queue may still hold entries for this wave
+    for (;;) {
+        const int n_node = __popcll(__ballot(w.n >= 0)), n_done = __popcll(__ballot(w.n == WIDE_DONE)), n_idle = __popcll(__ballot(w.n == IDLE));
+        const int n_leaf = 64 - n_node - n_done - n_idle;
+        // lanes a turnover would retire or give a walk: walks that ended, and -- while the queue still has entries -- lanes without a ray
+        const int n_wait = more ? n_done + n_idle : n_done;
+        if (n_node + n_leaf == 0 || n_wait >= PT_MESH_REFILL) {
+            // ---- turnover -----------------------------------------------------------------------------------------------------
+            if (w.n == WIDE_DONE) {                          // a walk ended: its key (meshKey's packing: object-space distance, geom, face)
+                const float t = w.face >= 0 ? w.tmin : -1.f;
+                if (t > 0.0f && t < 3.402823466e+38f) { const unsigned long long km = packKey(t, g, (uint32_t)w.face); key = km < key ? km : key; }
+                w.n = IDLE;
+                if (!mask) { keys[sa] = key; sa = -1; }      // every candidate mesh searched: the ray's hit is known
+            }
+            if (more) {                                      // free lanes take the next queue entries
+                const unsigned long long m_free = __ballot(sa < 0);
+                if (cur >= end && m_free) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(cursor, PT_MESH_CHUNK);
+                    cur = __builtin_amdgcn_readfirstlane(b);
+                    end = min(cur + PT_MESH_CHUNK, n);
+                    if (cur >= n) { more = false; cur = end = 0; }
+                }
+                const int take = min(__popcll(m_free), end - cur);
+                const int mine = wavePrefix(m_free, lane);
+                if (sa < 0 && mine < take) {
+                    const uint32_t e = items[cur + mine];
+                    if (e < slots) {                         // (fence: a queue entry is a slot of the stage, whatever wrote it)
+                        sa = (int32_t)e;
+                        key = keys[sa];
+                        mask = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask;
+                        if (!mask) sa = -1;                  // (cannot happen: pass 1 parks rays WITH candidates; nothing to search, the key stays)
+                    } else fence_report(p);
+                }
+                cur += take;
+            }
+            if (sa >= 0 && w.n == IDLE) {                    // set up the walk of the ray's next candidate mesh
+                Ray ray;
+                ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
+                ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
+                while (mask && w.n == IDLE) {
+                    g = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    const bool wideok = p.sc.bvh_wroot && p.sc.bvh_root && p.sc.bvh_root[g] >= 0 && p.sc.bvh_wroot[g] >= 0 && p.sc.bvh_wneed[g] <= bvh_stack;
+                    if (wideok) {
+                        const float *G = p.sc.gtab + g * GTAB_WORDS;
+                        float inv[12];
+#pragma unroll
+                        for (int k = 0; k < 12; k++) inv[k] = G[k];
+                        // (= multiplyMV(geom.inverseTransform, ., .) of meshTestCore: same products, same sums)
+                        const vec3 qo = mulRows(inv, ray.o, 1.0f), qd = normalize(mulRows(inv, ray.d, 0.0f));
+                        wideStart(w, p.sc.bvh_nodes, p.sc.bvh_root[g], p.sc.bvh_wroot[g], qo, qd);
+                        if (w.n == WIDE_DONE) w.n = IDLE;    // the root box is missed: no key from this mesh, on to the next
+                    } else {                                 // a mesh without a four-wide tree (too small for one, or its walk would not fit the stack): searched right here
+                        const unsigned long long km = meshKey(p.sc, p.sc.gtab, g, ray, -1, stack, 256);
+                        key = km < key ? km : key;
+                    }
+                }
+                if (w.n == IDLE) { keys[sa] = key; sa = -1; }      // no walk was started and no mesh is left
+            }
+            if (!more && !__ballot(sa >= 0)) break;
+            continue;
+        }
+        if (n_node >= PT_MESH_NMIN || n_leaf == 0) {
+            if (w.n >= 0) wideNodeStep(w, p.sc.bvh_wide, stack, 256);
+        } else {
+            if (w.n != WIDE_DONE && w.n != IDLE && w.n < 0) wideLeafStep<true>(w, p.sc.bvh_tris, stack, 256);
+        }
+    }
+}
+
+// Split mesh search, last part: one lane per parked ray finishes it -- nearest hit decoded from the final key, terminal cases, the
+// record completed in the slot the ray was parked in if it goes on, and the one word pass 2 needs left in lsrc[owner].  Dense lanes
+// that all do the same thing: the dependent face / texel loads of a textured mesh hit hide behind the other waves.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
+    BounceParams p = p_in;
+    p.sc.tri_lds = 0; p.sc.ntri_lds = 0;
     const int seg = blockIdx.y;
     const int iter = p.iter + seg * p.iter_stride;
     const int n = p.item_count[seg];
@@ -1151,18 +1269,13 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
     float *part = p.part ? p.part + p.seg_part * seg : nullptr;
     const bool batched = part != nullptr;
     const uint32_t slots = p.fence_slots;
-    const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int sa = (int)items[k];
         if ((uint32_t)sa >= slots) { fence_report(p); continue; }      // (fence: a queue entry is a slot of the stage, whatever wrote it)
         Ray ray;
         ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
         ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
-        unsigned long long key = keys[sa];
-        for (uint32_t m = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask; m; m &= m - 1) {
-            const unsigned long long km = meshKey(p.sc, p.sc.gtab, __ffs((int)m) - 1, ray, -1, pt_lds + threadIdx.x, 256);
-            key = km < key ? km : key;
-        }
+        const unsigned long long key = keys[sa];
         const int owner = st.mg()[sa], pix = st.pix()[sa];
         if ((uint32_t)owner >= slots) { fence_report(p); continue; }
         const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
@@ -1447,6 +1560,7 @@ struct ptx_tracer {
     TileMap tm{};
     int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, grid_seg = 0, cap = 0, cus = 0;
     bool grid_forced = false;                  // PTX_DEBUG_WG_PER_CU given: the grid is what it says for every kernel
+    int dbg_mesh_wg_per_cu = 0;                 // PTX_DEBUG_MESH_WG_PER_CU: workgroups per CU of k_mesh's grid (tuning experiments)
     int dbg_total_wg_per_cu = 0, dbg_nsets = 0; // PTX_DEBUG_TOTAL_WG_PER_CU / PTX_DEBUG_NSETS: tuning experiments (grid of a whole launch; sets of a short run)
     // device memory
     DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
@@ -1789,17 +1903,22 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         if (t->split_mesh) {
             bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
             bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
-            bp.item_count = t->d_item_count + seg0;
+            bp.item_count = t->d_item_count + 2 * seg0;          // (a launch set's K counts, then its K cursors: one memset)
+            bp.item_cursor = bp.item_count + K;
             bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
-            HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * (size_t)K, stream));
+            HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * 2 * (size_t)K, stream));
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
             // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy: as many entries as the longest walk needs
-            if (first) KT(2, hipLaunchKernelGGL(k_mesh<true>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
-            else KT(2, hipLaunchKernelGGL(k_mesh<false>, dim3(std::max(1, grid / K), K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack));
+            // (k_mesh's waves draw from the segment's queue until it is empty: one round of the kernel's occupancy is all the grid needs)
+            const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WAVES) / K);
+            if (first) KT(2, { hipLaunchKernelGGL(k_mesh<true>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack);
+                               hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
+            else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack);
+                         hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
             KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
-            bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
+            bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.item_cursor = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
         }
 
@@ -2208,6 +2327,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->force_fast = getenv("PTX_DEBUG_FORCE_FAST") != nullptr;
     if (const char *e = getenv("PTX_DEBUG_TOTAL_WG_PER_CU")) t->dbg_total_wg_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("PTX_DEBUG_NSETS")) t->dbg_nsets = std::max(0, atoi(e));
+    if (const char *e = getenv("PTX_DEBUG_MESH_WG_PER_CU")) t->dbg_mesh_wg_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
         HC(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
@@ -2250,7 +2370,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
             t->seg_items = (size_t)t->cap;
             HC(hipMalloc(&t->d_keys, sizeof(unsigned long long) * (size_t)t->cap * nseg));
             HC(hipMalloc(&t->d_items, sizeof(uint32_t) * t->seg_items * nseg));
-            HC(hipMalloc(&t->d_item_count, sizeof(int32_t) * nseg));
+            HC(hipMalloc(&t->d_item_count, sizeof(int32_t) * 2 * nseg));      // [nseg] counts (pass 1), [nseg] cursors (k_mesh)
             if (!getenv("PTX_DEBUG_NO_FIRST_FUSION")) {
                 HC(hipMalloc(&t->d_tile_done, sizeof(int32_t) * (size_t)t->maxTiles * nseg));
                 HC(hipMemset(t->d_tile_done, 0, sizeof(int32_t) * (size_t)t->maxTiles * nseg));
@@ -2775,6 +2895,16 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
             if (i % 64 == 63 || i == nrays - 1) { sum_group_max += group_max; group_max = 0; groups++; }
             if (wstack[(size_t)std::max(wneed, 1)] != 0x7fffffff) mismatches += 1000000;      // the walk overran the stack bound the builder computed
             if (f3 != f1 || memcmp(&t3, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&e0, &b0, 4) != 0 || memcmp(&e1, &b1, 4) != 0))) mismatches++;
+            {   // the same steps under the schedule of k_mesh's refilling waves: one node or ONE triangle per turn
+                WideWalk w;
+                wideStart(w, bb.nodes.data(), root, wroot, o, d);
+                while (w.n != WIDE_DONE) {
+                    if (w.n >= 0) wideNodeStep(w, bb.wide.data(), wstack.data(), 1);
+                    else wideLeafStep<true>(w, bb.tris.data(), wstack.data(), 1);
+                }
+                if (wstack[(size_t)std::max(wneed, 1)] != 0x7fffffff) mismatches += 1000000;
+                if (w.face != f1 || memcmp(&w.tmin, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&w.b0, &b0, 4) != 0 || memcmp(&w.b1, &b1, 4) != 0))) mismatches++;
+            }
         }
         face_loop[i] = f0; face_bvh[i] = f1;
         visited += vis;

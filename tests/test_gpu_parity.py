@@ -356,6 +356,32 @@ def test_full_size_c5_tile_of_an_8_way_split_against_oracle(gpu_product, O):
         T.close()
 
 
+def test_full_size_c5_20k_mesh_tile_of_an_8_way_split_against_oracle(gpu_product, O):
+    """The workload bench.py times as `c5` -- cornellSpaceship20k.txt (the 20 448-triangle stand-in: BVH, four-wide walk, split
+    mesh search) at 3840x2160 with depth of field -- compared with the ORACLE at that size, not only with the GPU's own plain loop:
+    one rank's interleaved 8-row blocks of the 8-way split (1/8 of 21.9 M ray-bounces x 20 448 triangles for the oracle's loop over all
+    faces, src/intersections.h:213-233; 16 threads, about the cost of the 1080p test above).  Identical partial frame, foreign rows
+    zero, identical rays per bounce."""
+    from mygpuraytracer_amd import multigpu
+    rank = 2
+    s, T = make_pair(gpu_product, O, "cornellSpaceship20k.txt", (3840, 2160), 8, depth_of_field=1, tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=8)
+    O.set_tile(multigpu.TILE_ROWS, rank, 8); O.pt_init()
+    try:
+        assert T.owned_pixels() == O.pixelcount()
+        O.set_threads(16)
+        O.iterate(1)
+        T.render(1, 1)
+        img = T.read_image()
+        assert beq(img, O.image())
+        assert T.stats()["rays_per_bounce"] == O.live_counts().tolist()
+        mine = np.repeat((np.arange(2160) // multigpu.TILE_ROWS) % 8 == rank, 3840)
+        assert not img[~mine].any() and img[mine].any()
+    finally:
+        O.set_threads(1)
+        O.set_tile(0, 0, 1)
+        T.close()
+
+
 RENDER_CASES = [
     ("c1_sphere", "sphere.txt", (64, 64), 4), ("c2_cornell_cache", "cornell.txt", (64, 64), 8), ("c3_glass", "cornellGlass.txt", (96, 54), 12),
     ("c4_obj", "cornellObj.txt", (96, 54), 8), ("c5_dof", "cornellGlass.txt", (96, 54), 8), ("nosort_obj", "cornellObj.txt", (96, 54), 8),
