@@ -210,16 +210,19 @@ def dropin_per_call(torch, pt, scene, dev_index, calls=96):
     return per_call, copy_ms
 
 
-def c5_per_iteration(pt, dev_index, iters=24):
+def c5_per_iteration(pt, dev_index, iters=72):
     """BASELINE configs[4] on ONE GPU: the cornellSpaceship layout at 3840x2160, depth 8, antialiasing + depth of field, textured
-    BVH mesh (the 20448-triangle procedural stand-in: the reference's .obj is missing), split mesh search.  ms per iteration."""
+    BVH mesh (the 20448-triangle procedural stand-in: the reference's .obj is missing), split mesh search.  ms per iteration over
+    `iters` iterations = six launch sets of 12 on the three streams (rounds 1-3 timed 24 = five sets of 5; with 12 iterations per set,
+    round 4's default at 4K, 24 would be two sets and no steady state: old / new library on one box, 24 iterations 1.215 / 1.20, 72
+    iterations 1.20 / 1.13 -- tools/gpu_c5_leg.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import ensure_standin_assets
     ensure_standin_assets()
     s = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=(3840, 2160), depth=8)
     s.apply_runcuda_camera()
     with pt.Tracer(s, depth_of_field=1, device=dev_index) as T:
-        T.render(1, 12)
+        T.render(1, 36)
         T.synchronize()
         r0 = T.stats()["rays_total"]
         t0 = time.perf_counter()
@@ -459,7 +462,7 @@ def main():
             if rank == 0:
                 ensure_standin_assets()
             barrier()
-            C5RES, C5STEPS = (3840, 2160), 24
+            C5RES, C5STEPS = (3840, 2160), 72
             s5 = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=C5RES, depth=8)
             s5.apply_runcuda_camera()
             img5 = multigpu.frame_buffer(C5RES[0], C5RES[1], world, device)
@@ -468,7 +471,7 @@ def main():
             if world > 1:
                 kw5.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
             with pt.Tracer(s5, external_image_ptr=img5.data_ptr(), **kw5) as T5:
-                T5.render(1, 12)
+                T5.render(1, 36)
                 T5.synchronize()
                 reduce_frame(img5.clone(), C5RES)
                 ct, cr, crays = timed_tile_run(T5, img5, C5RES, 100, C5STEPS)
@@ -617,7 +620,7 @@ def main():
             c5_ms, c5_rays = c5_per_iteration(pt, dev_index)
             out["c5_ms_per_iteration"] = c5_ms
             out["c5"] = dict(ms_per_iteration=c5_ms, rays_per_iteration=c5_rays, Mrays_per_s=c5_rays / c5_ms / 1e3,
-                             workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, 1 GPU (BASELINE configs[4] / C5)")
+                             workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, 1 GPU, 72 iterations after 36 (BASELINE configs[4] / C5)")
         except Exception as e:
             out["c5_ms_per_iteration"] = None
             out["c5"] = dict(error=str(e)[:200])

@@ -631,9 +631,10 @@ struct WideWalk {
     float tmin; int32_t face; float b0, b1;                  // best so far: distance, face (index inside the geom), its barycentrics
     int32_t sp, n;                                           // stack entries in use; what is in hand: >= 0 a wide node, WIDE_DONE, else a leaf reference
 };
-// Sets the walk up at the root; n = WIDE_DONE when the ray misses the root box.
-PT_HD void wideStart(WideWalk &w, const BvhQuad *__restrict__ nodes, int root, int wroot, vec3 o, vec3 d, int *visited = nullptr) {
-    const RaySlab rs = makeRaySlab(o, d, bvhSlack(nodes[2 * root], nodes[2 * root + 1], o));
+// Sets the walk up at the root (A, B = the two quads of the binary tree's root node: its box, for the slack and the first test);
+// n = WIDE_DONE when the ray misses the root box.
+PT_HD void wideStart(WideWalk &w, const BvhQuad &A, const BvhQuad &B, int wroot, vec3 o, vec3 d, int *visited = nullptr) {
+    const RaySlab rs = makeRaySlab(o, d, bvhSlack(A, B, o));
     w.o = o; w.d = d;
     w.tmin = 3.402823466e+38f; w.face = -1; w.b0 = 0.f; w.b1 = 0.f;
     w.ix = rs.ix; w.iy = rs.iy; w.iz = rs.iz;
@@ -642,7 +643,7 @@ PT_HD void wideStart(WideWalk &w, const BvhQuad *__restrict__ nodes, int root, i
     w.sp = 0;
     float tn;
     if (visited) ++*visited;
-    w.n = slabEntry(nodes[2 * root], nodes[2 * root + 1], rs, w.tmin, tn) ? wroot : WIDE_DONE;
+    w.n = slabEntry(A, B, rs, w.tmin, tn) ? wroot : WIDE_DONE;
 }
 // One wide node (w.n >= 0): four box tests, the entries that are hit sorted by entry distance, the nearest taken in hand, the others
 // pushed farthest first -- leaves and inner entries alike.  Afterwards w.n is an inner node, a leaf reference or WIDE_DONE.
@@ -732,7 +733,7 @@ PT_HD float bvhNearestWide(const BvhQuad *__restrict__ nodes, const BvhWide4 *__
     // four times per node any lane of the wave visits.  A hit prunes through tmin: every box is tested against the best distance when
     // its node is visited.
     WideWalk w;
-    wideStart(w, nodes, root, wroot, o, d, visited);
+    wideStart(w, nodes[2 * root], nodes[2 * root + 1], wroot, o, d, visited);
     for (;;) {
         while (w.n >= 0) wideNodeStep(w, wide, stack, stride, visited, trace);
         if (w.n == WIDE_DONE) break;

@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 // gave every lane ONE ray: a wave then issues for its slowest lane, 19 % of the lanes active per vector instruction (round 3's
 // counters; tools/mesh_walk_sim.cpp reproduces 16 % on the CPU from the walks' step sequences).  Ordering the queue by direction
 // octant / entry cell so that neighbouring lanes walk alike buys 5-10 % (same simulator: the spread is in the LENGTHS, not in the
-// paths).  So a wave now keeps its lanes busy instead: it draws chunks of the queue (one global atomic per PT_MESH_CHUNK entries and
+// paths).  So a wave now keeps its lanes busy instead: it draws chunks of the queue (one global atomic per PT_MESHQ_CHUNK entries and
 // wave, on a per-segment cursor), every lane holds the walk state of one ray (WideWalk, pt_device.h), and the wave alternates
 //   * a NODE round  -- the lanes whose walk holds an inner node do one four-wide node step -- while at least PT_MESH_NMIN lanes do, or
 //                      no lane holds a leaf;
@@ -1150,8 +1150,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 // again, one dense lane per queue entry: its code and registers do not ride along with the walks.
 // Exit: every wave ends when the cursor has passed the queue's end and none of its lanes holds a ray -- each round advances every lane
 // it runs, each turnover consumes queue entries or retires rays, so the loop ends for any queue content (bad entries are fenced).
-#ifndef PT_MESH_CHUNK
-#define PT_MESH_CHUNK 256     // queue entries a wave reserves per global atomic
+#ifndef PT_MESHQ_CHUNK      // (not PT_MESH_CHUNK: that is pt_device.h's faces-per-lane of the small meshes -- the first build of this kernel
+                           // took ITS value, 4, for the chunk: one global atomic per four rays, 8x slower, results right)
+#define PT_MESHQ_CHUNK 128    // queue entries a wave reserves per global atomic (64: +1 %, 32: +30 % -- the cursor is one address per segment)
 #endif
 #ifndef PT_MESH_REFILL
 #define PT_MESH_REFILL 16     // lanes without a walk that trigger a turnover
@@ -1159,10 +1160,14 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #ifndef PT_MESH_NMIN
 #define PT_MESH_NMIN 32       // lanes holding an inner node that make the next round a node round
 #endif
+#ifndef PT_MESH_ONE_TRI
+#define PT_MESH_ONE_TRI 0     // 1: a leaf round tests ONE triangle of the leaf in hand; 0: all of them (measured: 0.54 against 0.61 ms per
+                              // iteration at 4K -- the kernel waits for memory more than it issues, and a leaf's triangles share cache lines)
+#endif
+constexpr int MESH_GEOM_WORDS = 20;      // per geom in k_mesh's LDS: inverseTransform rows 0-2 (12), root box lo / hi (6), wide root (-1: not searched here), pad
 template <bool FIRST>
 __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams p_in, int bvh_stack) {
-    BounceParams p = p_in;
-    p.sc.tri_lds = 0; p.sc.ntri_lds = 0; p.sc.bvh_stack = bvh_stack;      // (no LDS tables in this kernel; LDS = the walks' stacks)
+    const BounceParams &p = p_in;
     const int seg = blockIdx.y;
     const int n = p.item_count[seg];
     const int lane = threadIdx.x & 63;
@@ -1171,12 +1176,31 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
     unsigned long long *keys = p.keys + p.seg_keys * seg;
     int32_t *cursor = p.item_cursor + seg;
     const uint32_t slots = p.fence_slots;
-    const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
+    const int ngeoms = p.sc.ngeoms < 32 ? p.sc.ngeoms : 32;
+    const uint32_t geom_mask = ngeoms >= 32 ? 0xffffffffu : (1u << ngeoms) - 1u;
+    // dynamic LDS: [bvh_stack][256] the walks' stacks, then what a walk's set-up needs per geom -- one LDS read where the geom table, the
+    // three per-geom tree tables and the root node were a chain of dependent global loads in front of every walk
     int32_t *stack = pt_lds + threadIdx.x;
+    float *gl = reinterpret_cast<float *>(pt_lds + (size_t)bvh_stack * 256);
+    if ((int)threadIdx.x < ngeoms) {
+        const int gi = threadIdx.x;
+        float *o = gl + gi * MESH_GEOM_WORDS;
+        const float *G = p.sc.gtab + gi * GTAB_WORDS;
+        for (int k = 0; k < 12; k++) o[k] = G[k];
+        const int root = p.sc.bvh_root ? p.sc.bvh_root[gi] : -1;
+        const bool wideok = root >= 0 && p.sc.bvh_wroot && p.sc.bvh_wroot[gi] >= 0 && p.sc.bvh_wneed[gi] <= bvh_stack;
+        BvhQuad A, B;
+        A.x = A.y = A.z = B.x = B.y = B.z = 0.f; A.w = B.w = 0;
+        if (wideok) { A = p.sc.bvh_nodes[2 * root]; B = p.sc.bvh_nodes[2 * root + 1]; }
+        o[12] = A.x; o[13] = A.y; o[14] = A.z; o[15] = B.x; o[16] = B.y; o[17] = B.z;
+        o[18] = __int_as_float(wideok ? p.sc.bvh_wroot[gi] : -1); o[19] = 0.f;
+    }
+    __syncthreads();
     constexpr int32_t IDLE = (int32_t)0x80000001;             // (no leaf reference looks like this either: count 0)
-    // per-lane state: the ray in hand (sa: its stage slot; < 0: none), the meshes still to search, the best key so far, the walk
+    // per-lane state: the ray in hand (sa: its stage slot; < 0: none), the meshes still to search, the ones left to k_finish, the best
+    // key so far, the walk
     int32_t sa = -1, g = 0;
-    uint32_t mask = 0;
+    uint32_t mask = 0, rest = 0;
     unsigned long long key = KEY_NONE;
     WideWalk w;
     w.n = IDLE; w.sp = 0; w.tmin = 0.f; w.face = -1; w.b0 = w.b1 = 0.f;
@@ -1194,53 +1218,60 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
                 const float t = w.face >= 0 ? w.tmin : -1.f;
                 if (t > 0.0f && t < 3.402823466e+38f) { const unsigned long long km = packKey(t, g, (uint32_t)w.face); key = km < key ? km : key; }
                 w.n = IDLE;
-                if (!mask) { keys[sa] = key; sa = -1; }      // every candidate mesh searched: the ray's hit is known
             }
             if (more) {                                      // free lanes take the next queue entries
-                const unsigned long long m_free = __ballot(sa < 0);
+                const unsigned long long m_free = __ballot(w.n == IDLE && !mask);      // (no walk, no mesh left: the ray in hand, if any, retires below)
                 if (cur >= end && m_free) {
                     int b = 0;
-                    if (lane == 0) b = atomicAdd(cursor, PT_MESH_CHUNK);
+                    if (lane == 0) b = atomicAdd(cursor, PT_MESHQ_CHUNK);
                     cur = __builtin_amdgcn_readfirstlane(b);
-                    end = min(cur + PT_MESH_CHUNK, n);
+                    end = min(cur + PT_MESHQ_CHUNK, n);
                     if (cur >= n) { more = false; cur = end = 0; }
                 }
                 const int take = min(__popcll(m_free), end - cur);
                 const int mine = wavePrefix(m_free, lane);
-                if (sa < 0 && mine < take) {
-                    const uint32_t e = items[cur + mine];
-                    if (e < slots) {                         // (fence: a queue entry is a slot of the stage, whatever wrote it)
-                        sa = (int32_t)e;
-                        key = keys[sa];
-                        mask = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask;
-                        if (!mask) sa = -1;                  // (cannot happen: pass 1 parks rays WITH candidates; nothing to search, the key stays)
-                    } else fence_report(p);
+                if (w.n == IDLE && !mask) {
+                    if (sa >= 0) {                           // every candidate mesh of the ray in hand is searched (or left to k_finish): its key is final here
+                        keys[sa] = key;
+                        st.nx()[sa] = __int_as_float((int)rest);
+                        sa = -1;
+                    }
+                    if (mine < take) {
+                        const uint32_t e = items[cur + mine];
+                        if (e < slots) {                     // (fence: a queue entry is a slot of the stage, whatever wrote it)
+                            sa = (int32_t)e;
+                            key = keys[sa];
+                            mask = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask;
+                            rest = 0;
+                        } else fence_report(p);
+                    }
                 }
                 cur += take;
+            } else if (w.n == IDLE && !mask && sa >= 0) {
+                keys[sa] = key;
+                st.nx()[sa] = __int_as_float((int)rest);
+                sa = -1;
             }
-            if (sa >= 0 && w.n == IDLE) {                    // set up the walk of the ray's next candidate mesh
-                Ray ray;
-                ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
-                ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
+            if (sa >= 0 && w.n == IDLE) {                    // (mask != 0 here) set up the walk of the ray's next candidate mesh
+                const vec3 ro = V3(st.px()[sa], st.py()[sa], st.pz()[sa]), rd = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
                 while (mask && w.n == IDLE) {
                     g = __ffs((int)mask) - 1;
                     mask &= mask - 1;
-                    const bool wideok = p.sc.bvh_wroot && p.sc.bvh_root && p.sc.bvh_root[g] >= 0 && p.sc.bvh_wroot[g] >= 0 && p.sc.bvh_wneed[g] <= bvh_stack;
-                    if (wideok) {
-                        const float *G = p.sc.gtab + g * GTAB_WORDS;
+                    const float *L = gl + g * MESH_GEOM_WORDS;
+                    const int wroot = __float_as_int(L[18]);
+                    if (wroot >= 0) {
                         float inv[12];
 #pragma unroll
-                        for (int k = 0; k < 12; k++) inv[k] = G[k];
+                        for (int k = 0; k < 12; k++) inv[k] = L[k];
                         // (= multiplyMV(geom.inverseTransform, ., .) of meshTestCore: same products, same sums)
-                        const vec3 qo = mulRows(inv, ray.o, 1.0f), qd = normalize(mulRows(inv, ray.d, 0.0f));
-                        wideStart(w, p.sc.bvh_nodes, p.sc.bvh_root[g], p.sc.bvh_wroot[g], qo, qd);
+                        const vec3 qo = mulRows(inv, ro, 1.0f), qd = normalize(mulRows(inv, rd, 0.0f));
+                        BvhQuad A, B;
+                        A.x = L[12]; A.y = L[13]; A.z = L[14]; A.w = 0; B.x = L[15]; B.y = L[16]; B.z = L[17]; B.w = 0;
+                        wideStart(w, A, B, wroot, qo, qd);
                         if (w.n == WIDE_DONE) w.n = IDLE;    // the root box is missed: no key from this mesh, on to the next
-                    } else {                                 // a mesh without a four-wide tree (too small for one, or its walk would not fit the stack): searched right here
-                        const unsigned long long km = meshKey(p.sc, p.sc.gtab, g, ray, -1, stack, 256);
-                        key = km < key ? km : key;
-                    }
+                    } else rest |= 1u << g;                  // a mesh without a four-wide tree (too small for one, or its walk would not fit the
+                                                             // stack): k_finish searches it, with the loop or the stackless walk
                 }
-                if (w.n == IDLE) { keys[sa] = key; sa = -1; }      // no walk was started and no mesh is left
             }
             if (!more && !__ballot(sa >= 0)) break;
             continue;
@@ -1248,7 +1279,7 @@ __global__ __launch_bounds__(256, PT_MESH_WAVES) void k_mesh(const BounceParams 
         if (n_node >= PT_MESH_NMIN || n_leaf == 0) {
             if (w.n >= 0) wideNodeStep(w, p.sc.bvh_wide, stack, 256);
         } else {
-            if (w.n != WIDE_DONE && w.n != IDLE && w.n < 0) wideLeafStep<true>(w, p.sc.bvh_tris, stack, 256);
+            if (w.n != WIDE_DONE && w.n != IDLE && w.n < 0) wideLeafStep<PT_MESH_ONE_TRI != 0>(w, p.sc.bvh_tris, stack, 256);
         }
     }
 }
@@ -1269,13 +1300,20 @@ __global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
     float *part = p.part ? p.part + p.seg_part * seg : nullptr;
     const bool batched = part != nullptr;
     const uint32_t slots = p.fence_slots;
+    const uint32_t geom_mask = p.sc.ngeoms >= 32 ? 0xffffffffu : (1u << p.sc.ngeoms) - 1u;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int sa = (int)items[k];
         if ((uint32_t)sa >= slots) { fence_report(p); continue; }      // (fence: a queue entry is a slot of the stage, whatever wrote it)
         Ray ray;
         ray.o = V3(st.px()[sa], st.py()[sa], st.pz()[sa]);
         ray.d = V3(st.dx()[sa], st.dy()[sa], st.dz()[sa]);
-        const unsigned long long key = keys[sa];
+        unsigned long long key = keys[sa];
+        // the candidate meshes k_mesh did not search (no four-wide tree: small meshes of a split scene, trees too deep for the walks' stack):
+        // the plain loop or the stackless walk, same keys, same minimum
+        for (uint32_t m = (uint32_t)__float_as_int(st.nx()[sa]) & geom_mask; m; m &= m - 1) {
+            const unsigned long long km = meshKey(p.sc, p.sc.gtab, __ffs((int)m) - 1, ray);
+            key = km < key ? km : key;
+        }
         const int owner = st.mg()[sa], pix = st.pix()[sa];
         if ((uint32_t)owner >= slots) { fence_report(p); continue; }
         const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
@@ -1911,9 +1949,9 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy: as many entries as the longest walk needs
             // (k_mesh's waves draw from the segment's queue until it is empty: one round of the kernel's occupancy is all the grid needs)
             const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WAVES) / K);
-            if (first) KT(2, { hipLaunchKernelGGL(k_mesh<true>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack);
+            if (first) KT(2, { hipLaunchKernelGGL(k_mesh<true>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
                                hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
-            else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * (size_t)t->bvh_stack * 256, stream, bp, t->bvh_stack);
+            else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
                          hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
             KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
@@ -2296,12 +2334,17 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     // ~16 GB).  With the first-bounce cache the iterations of a batch all start from the one cached bounce-0 stream
     int kmax = opt.batch;
     if (kmax <= 0) {
-        // about 24 M paths per launch set: 12 iterations of a 1080p frame, up to 32 of a small frame or of one rank's tile
-        // (1/8 of 1080p: 0.058 -> 0.048 ms per iteration with 32 instead of 8), fewer when the buffers would not fit ~16 GB
+        // about 24 M paths per launch set, at least 12 iterations: 12 of a 1080p frame, up to 32 of a small frame or of one rank's tile
+        // (1/8 of 1080p: 0.058 -> 0.048 ms per iteration with 32 instead of 8), fewer only where the streams of all launch sets in
+        // flight (two stages of 19 words + radiance + the split search's keys and queue = 176 B per path and iteration) would pass
+        // 64 GB of the 288.  Round 4: 12 instead of 5 at 3840x2160 (the rule was 16 GB with a guessed 400 B per path): every kernel of the
+        // split bounce gets 2.4x the work per launch -- C5 1.23 -> 1.17 ms per iteration with round 3's kernels, and what the refilling
+        // k_mesh needs: 1.4 M parked rays per launch instead of 0.6 M for the chip's 330 k lanes.
         const long long owned = std::max(t->tm.owned, 1);
         long long want = ((24LL << 20) + owned / 2) / owned;
-        want = std::min<long long>(32, std::max<long long>(8, want));
-        kmax = (int)std::min<long long>(want, std::max<long long>(1, (16LL << 30) / (400LL * owned)));
+        want = std::min<long long>(32, std::max<long long>(12, want));
+        const long long nl = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
+        kmax = (int)std::min<long long>(want, std::max<long long>(1, (64LL << 30) / (176LL * nl * owned)));
     }
     if (kmax > 64) kmax = 64;
     // the per-tile prefix tables grow with bins x tiles x iterations in flight: keep them under 4 GiB by putting fewer
@@ -2897,7 +2940,7 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
             if (f3 != f1 || memcmp(&t3, &t_bvh[i], 4) != 0 || (f1 >= 0 && (memcmp(&e0, &b0, 4) != 0 || memcmp(&e1, &b1, 4) != 0))) mismatches++;
             {   // the same steps under the schedule of k_mesh's refilling waves: one node or ONE triangle per turn
                 WideWalk w;
-                wideStart(w, bb.nodes.data(), root, wroot, o, d);
+                wideStart(w, bb.nodes[2 * (size_t)root], bb.nodes[2 * (size_t)root + 1], wroot, o, d);
                 while (w.n != WIDE_DONE) {
                     if (w.n >= 0) wideNodeStep(w, bb.wide.data(), wstack.data(), 1);
                     else wideLeafStep<true>(w, bb.tris.data(), wstack.data(), 1);

@@ -6,7 +6,7 @@ slowest rank taken; the exchange is the part one GPU cannot show in full, so it 
     (or reduce) + unpack + the closing barrier -- the software cost of the collective calls on this box;
   * modelled: the bytes that have to cross xGMI into rank 0, at LINK_GBPS per link (gather: (N-1) packs over N-1 links in
     parallel = one pack time; reduce: ring, 2(N-1)/N of the buffer over one link).
-Prints one JSON line per N and a markdown table, for C4 (bench.py's timed region) and for C5 at 3840x2160 (its `c5` leg: 24 steps after 12;
+Prints one JSON line per N and a markdown table, for C4 (bench.py's timed region) and for C5 at 3840x2160 (its `c5` leg: 72 steps after 36;
 PREDICT_ONLY=C4 or C5 picks one).   gpu_scale_predict.py [K] [W]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,9 +25,9 @@ if have_dist:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import ensure_standin_assets
 ensure_standin_assets()
-# the two workloads bench.py --gpus N reports: C4 (the timed region: K steps after W) and C5 (its `c5` leg: 24 steps after 12, at 4K)
+# the two workloads bench.py --gpus N reports: C4 (the timed region: K steps after W) and C5 (its `c5` leg: 72 steps after 36, at 4K)
 WORKLOADS = [("C4", "cornellObj.txt", (1920, 1080), {}, K, Wm, True),
-             ("C5", "cornellSpaceship20k.txt", (3840, 2160), dict(depth_of_field=1), 24, 12, False)]
+             ("C5", "cornellSpaceship20k.txt", (3840, 2160), dict(depth_of_field=1), 72, 36, False)]
 if os.environ.get("PREDICT_ONLY"):
     WORKLOADS = [w for w in WORKLOADS if w[0] in os.environ["PREDICT_ONLY"].split(",")]
 

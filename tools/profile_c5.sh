@@ -6,9 +6,10 @@ R=$GRAFT_REPO_ROOT
 SC=${1:-cornellSpaceship20k.txt}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/c5_stats $R/gpurun_out/c5_fetch $R/gpurun_out/c5_write
-ITERS=${C5_ITERS:-64}
+ITERS=${C5_ITERS:-60}
+export C5_ITERS=$ITERS
 for k in fetch write; do
-  echo "rocprofv3 --pmc $(echo $k | tr a-z A-Z)_SIZE (a pass of its own, no tracing) -- python3 tools/gpu_c5_profile.py $SC: $SC 3840x2160 depth 8, AA + DoF, $ITERS iterations, lanes = 1 (one launch set at a time); a launch covers the iterations of one launch set at 4K (batch = 5: $ITERS iterations run as sets of 5 and a remainder), pass 1 / k_mesh / pass 2 of the split bounce apart" > $R/gpurun_out/c5_${k}_how.txt
+  echo "rocprofv3 --pmc $(echo $k | tr a-z A-Z)_SIZE (a pass of its own, no tracing) -- python3 tools/gpu_c5_profile.py $SC: $SC 3840x2160 depth 8, AA + DoF, $ITERS iterations, lanes = 1 (one launch set at a time); a launch covers the iterations of one launch set at 4K (batch = 12 since round 4: $ITERS iterations = $((ITERS / 12)) sets of 12 and a remainder of $((ITERS % 12))), pass 1 / k_mesh / pass 2 of the split bounce apart" > $R/gpurun_out/c5_${k}_how.txt
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c5_stats -- python3 $R/tools/gpu_c5_profile.py $SC > $R/gpurun_out/c5_stats.log 2>&1
 echo "stats done"
