@@ -928,7 +928,10 @@ PT_HD vec3 mulRows(const float *r, vec3 v, float w) {
 // Candidate mask of one ray: bit i set <=> geom i's conservative world box is reached (uniform loop over geoms, two
 // boxes per trip so their scalar loads overlap; 8 floats per box: min xyz, pad, max xyz, pad).  Which of the set bits
 // are cubes, spheres or meshes is a per-scene constant (sc.cube_bits / sphere_bits / mesh_bits).
-PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
+// SUBSET: only the geoms whose bit is set in `subset` are tested (a wave-uniform mask: the camera-ray bounce knows per tile which geoms
+// its pixels can see at all, k_bounce's tile_geoms); the others' bits stay 0.
+template <bool SUBSET = false>
+PT_DEV uint32_t cullMask(const DScene &sc, Ray ray, uint32_t subset = 0xffffffffu) {
     typedef const __attribute__((address_space(4))) float cfloat;
     cfloat *ab = (cfloat *)sc.aabb;
     const float tiny = 1e-20f;
@@ -943,21 +946,37 @@ PT_DEV uint32_t cullMask(const DScene &sc, Ray ray) {
     const float ox = -(ray.o.x * ix), oy = -(ray.o.y * iy), oz = -(ray.o.z * iz);
     uint32_t mask = 0;
     const int n = sc.ngeoms;
+    auto slab = [&](const float *bx) {
+        const float x0 = __builtin_fmaf(bx[0], ix, ox), x1 = __builtin_fmaf(bx[4], ix, ox);
+        const float y0 = __builtin_fmaf(bx[1], iy, oy), y1 = __builtin_fmaf(bx[5], iy, oy);
+        const float z0 = __builtin_fmaf(bx[2], iz, oz), z1 = __builtin_fmaf(bx[6], iz, oz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        return !((tf < tn) || (tf < 0.0f));      // any NaN => not culled
+    };
+    if (SUBSET) {
+        // (a scalar loop over the set bits, two boxes per trip like the plain loop; n <= 32 wherever the masks are in use)
+        uint32_t todo = __builtin_amdgcn_readfirstlane(n >= 32 ? subset : subset & ((1u << n) - 1u));
+        while (todo) {
+            const int i = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int j = todo ? __builtin_ctz(todo) : i;
+            todo &= todo - 1;                    // (0 & anything = 0: harmless when j == i)
+            float bx[2][8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[j * 8 + k]; }
+            mask |= slab(bx[0]) ? (1u << i) : 0u;
+            mask |= slab(bx[1]) ? (1u << j) : 0u;
+        }
+        return mask;
+    }
     for (int i = 0; i < n; i += 2) {
         const int j = i + 1 < n ? i + 1 : i;
         float bx[2][8];
 #pragma unroll
         for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[j * 8 + k]; }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const float x0 = __builtin_fmaf(bx[h][0], ix, ox), x1 = __builtin_fmaf(bx[h][4], ix, ox);
-            const float y0 = __builtin_fmaf(bx[h][1], iy, oy), y1 = __builtin_fmaf(bx[h][5], iy, oy);
-            const float z0 = __builtin_fmaf(bx[h][2], iz, oz), z1 = __builtin_fmaf(bx[h][6], iz, oz);
-            const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-            const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-            const bool culled = (tf < tn) || (tf < 0.0f);      // any NaN => not culled
-            mask |= culled ? 0u : (1u << (h ? j : i));
-        }
+        for (int h = 0; h < 2; h++) mask |= slab(bx[h]) ? (1u << (h ? j : i)) : 0u;
     }
     return mask;
 }

@@ -227,6 +227,7 @@ struct BounceParams {
     unsigned long long *keys; uint32_t *items; int32_t *item_count;
     int32_t *item_cursor;                  // one int per segment, after the counts: where k_mesh's waves draw their next chunk of the queue
     size_t seg_keys, seg_items;            // per-segment strides of keys / items; item_count has one int per segment
+    const uint32_t *tile_geoms;            // first bounce: [tile] bit g = some pixel of the tile may see geom g (NULL: no information)
     int32_t *tile_done;                    // split first bounce: [segment][tile] 1 = pass 1 finished the tile (no ray of it reaches a mesh's box)
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
@@ -338,10 +339,10 @@ constexpr int ITEMS_PER_PASS = 4;                      // pairs a ray may contri
 #endif
 // DEFER: the mesh pairs are not worked off here; the caller gets the best key over cubes and spheres and the ray's
 // mesh candidates (split mesh search, see k_mesh), and `hit` is left alone.
-template <bool DEFER, bool PARK = false>
+template <bool DEFER, bool PARK = false, bool SUBSET = false>
 __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray ray, bool need_uv, Hit &hit, int32_t *scratch,
                                               int32_t *tcnt, int &q, int tid, int lane, int wave, unsigned long long &key_out,
-                                              uint32_t &mesh_out TI_ARGS) {
+                                              uint32_t &mesh_out TI_ARGS, uint32_t subset = 0xffffffffu) {
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
@@ -350,7 +351,7 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     constexpr int CAP = ITEMS_PER_PASS * TILE;
     uint32_t cube_mask = 0, sph_mask = 0, mesh_mask = 0;
     if (alive) {
-        const uint32_t m = cullMask(sc, ray);
+        const uint32_t m = cullMask<SUBSET>(sc, ray, subset);
         cube_mask = m & sc.cube_bits; sph_mask = m & sc.sphere_bits; mesh_mask = m & sc.mesh_bits;
     }
     mesh_out = mesh_mask;
@@ -767,6 +768,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #endif
         const int i = tile * TILE + tid;
         bool alive = i < n_in;
+        // camera rays: the geoms this tile's 256 pixels can see at all (host, update_tile_geoms: conservative screen rectangles of the
+        // geoms' world boxes): the per-ray candidate masks test only these -- most tiles see two or three of a Cornell scene's seven
+        uint32_t tile_subset = 0xffffffffu;
+        if (FIRST && MODE != 2 && p.tile_geoms) tile_subset = ((const __attribute__((address_space(4))) uint32_t *)p.tile_geoms)[tile];
         InRec cur;
         uint32_t li4 = 0;
         int idx_base = 0;
@@ -817,7 +822,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 int x, y;
                 owned_pixel(p.tm, i, x, y);
                 pix = i;                 // the slot; the pixel is (x, y)
-                generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
+                // (a tile that sees no geom at all: its rays miss whatever they are -- none is generated, none is tested)
+                if (tile_subset != 0u) generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
                 fetch(li4, idx_base, cur);
@@ -849,11 +855,25 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         // computeIntersections(b) + the terminal cases of shadeFakeMaterial(b)
         Hit hit;
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
+        if (FIRST && MODE == 0 && tile_subset == 0u) {
+            // Camera rays of a tile into which no geom's box projects (the wide margins of the Cornell frames: over half of C4's tiles):
+            // every ray misses.  Nothing is generated, tested, ranked or stored -- the paths end black (their slot of the radiance buffer is
+            // written), the tile's keys say "no record", and what moves on is the count of survivors in the miss bin (material 0), which
+            // the stream indices of the next bounce and the ray statistics are made of.  (The per-tile prefix tables are only ever read
+            // for stored paths: this tile has none.)
+            int mbin = 0;
+            bool mpend = false;
+            if (alive) classifyRay(hit, ps, pix, mbin, mpend);
+            st_u(stage.idx(), (uint32_t)i << 2, (int32_t)-1);
+            if (tid == 0) run_all[p.sort ? p.sc.nmats - 1 : 0] += min(TILE, n_in - tile * TILE);
+            continue;
+        }
         {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
             uint32_t mesh_cand = 0;
             if (MODE == 1) {
-                tileIntersect<true>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
+                if (FIRST && tile_subset == 0u) __syncthreads();      // (the histogram is zeroed: what tileIntersect's barriers see to otherwise)
+                else tileIntersect<true, false, FIRST>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS, tile_subset);
                 // Camera rays are coherent: most tiles of the first bounce (256 neighbouring pixels of a row) hold no ray that
                 // reaches a mesh's box at all.  Such a tile is finished right here -- winner's normal, terminal cases,
                 // ranking, in-tile sort, stage write, as in the unsplit kernel -- instead of being parked and picked up again;
@@ -916,18 +936,20 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 // stays at 4 waves, where parking only costs LDS traffic; MODE 2 fits 96 registers as it is.)
                 constexpr bool PARK = FAST && PT_PARK_STATE;
                 float *park = reinterpret_cast<float *>(rec) + 12 * TILE;
-                if (PARK) {
-                    park[0 * TILE + tid] = ps.color.x; park[1 * TILE + tid] = ps.color.y; park[2 * TILE + tid] = ps.color.z;
-                    rec[15 * TILE + tid] = pix;
-                }
-                tileIntersect<false, PARK>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS);
-                if (PARK) {
-                    asm volatile("" ::: "memory");
-                    const float *rb = reinterpret_cast<const float *>(rec);
-                    ps.o = V3(rb[0 * TILE + tid], rb[1 * TILE + tid], rb[2 * TILE + tid]);
-                    ps.d = V3(rb[3 * TILE + tid], rb[4 * TILE + tid], rb[5 * TILE + tid]);
-                    ps.color = V3(park[0 * TILE + tid], park[1 * TILE + tid], park[2 * TILE + tid]);
-                    pix = rec[15 * TILE + tid];
+                {
+                    if (PARK) {
+                        park[0 * TILE + tid] = ps.color.x; park[1 * TILE + tid] = ps.color.y; park[2 * TILE + tid] = ps.color.z;
+                        rec[15 * TILE + tid] = pix;
+                    }
+                    tileIntersect<false, PARK, FIRST>(p.sc, alive, ray, p.uses_uv != 0, hit, rec, tcnt, tq, tid, lane, wave, key, mesh_cand TI_PASS, tile_subset);
+                    if (PARK) {
+                        asm volatile("" ::: "memory");
+                        const float *rb = reinterpret_cast<const float *>(rec);
+                        ps.o = V3(rb[0 * TILE + tid], rb[1 * TILE + tid], rb[2 * TILE + tid]);
+                        ps.d = V3(rb[3 * TILE + tid], rb[4 * TILE + tid], rb[5 * TILE + tid]);
+                        ps.color = V3(park[0 * TILE + tid], park[1 * TILE + tid], park[2 * TILE + tid]);
+                        pix = rec[15 * TILE + tid];
+                    }
                 }
             }
             else {
@@ -1614,6 +1636,8 @@ struct ptx_tracer {
     int32_t *d_totals = nullptr;                         // [maxBounces][2][nbins] then [maxBounces][2][nbins][nsuper]
     int32_t *d_super = nullptr;                          // (points into d_totals' allocation)
     float *d_tri9 = nullptr, *d_gtab = nullptr, *d_aabb = nullptr;
+    std::vector<float> h_aabb;                           // host copy of the world boxes (update_tile_geoms)
+    uint32_t *d_tile_geoms = nullptr; bool tile_geoms_valid = false;      // BounceParams::tile_geoms of the current camera
     uint32_t cube_bits = 0, sphere_bits = 0, mesh_bits = 0;   // geoms 0..31 by kind, for the candidate masks
     BvhQuad *d_bvh_nodes = nullptr; float *d_bvh_tris = nullptr; int32_t *d_bvh_root = nullptr, *d_bvh_depth = nullptr;   // pt_bvh.h (NULL: no mesh has one)
     BvhWide4 *d_bvh_wide = nullptr; int32_t *d_bvh_wroot = nullptr, *d_bvh_wneed = nullptr;                                  // four-wide nodes of the same trees (k_mesh)
@@ -1744,12 +1768,86 @@ void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6
     }
 }
 
+// Which geoms can the camera rays of a tile reach at all?  Per geom the pixel rectangle that its conservative world box projects
+// into (double precision, widened by the antialiasing jitter and two more pixels); a corner at or behind the eye plane makes it the
+// whole frame.  A tile is 256 consecutive OWNED pixels: one span of a row, or -- when it wraps -- whole rows.  Bit g of a tile's
+// word is cleared only when geom g's rectangle misses the tile's: a superset of what any of its rays can hit, so the candidate
+// masks built from it (cullMask<SUBSET>) hold exactly the bits the full loop would set for those rays.  Not with depth of field
+// (rays then start anywhere on the lens), nor where the candidate masks are off; recomputed when the camera changes.
+int update_tile_geoms(ptx_tracer *t) {
+    t->tile_geoms_valid = false;
+    if (!t->cull || t->opt.depth_of_field || t->ngeoms > 32 || t->ngeoms < 1 || getenv("PTX_DEBUG_NO_TILE_GEOMS")) return PTX_OK;
+    const DCamera &c = t->cam;
+    const int W = c.resx, H = c.resy;
+    // p - eye = l * (view - R sx - U sy),  R = right * pixelLength.x, U = up * pixelLength.y,  sx = x - W/2, sy = y - H/2  (generateRay)
+    const double V[3] = {c.view[0], c.view[1], c.view[2]};
+    const double R[3] = {(double)c.right[0] * c.pixelLength[0], (double)c.right[1] * c.pixelLength[0], (double)c.right[2] * c.pixelLength[0]};
+    const double U[3] = {(double)c.up[0] * c.pixelLength[1], (double)c.up[1] * c.pixelLength[1], (double)c.up[2] * c.pixelLength[1]};
+    // solve [V  -R  -U] (l, l sx, l sy)^T = p - eye by Cramer's rule
+    auto det3 = [](const double *a, const double *b, const double *d) {
+        return a[0] * (b[1] * d[2] - b[2] * d[1]) - b[0] * (a[1] * d[2] - a[2] * d[1]) + d[0] * (a[1] * b[2] - a[2] * b[1]);
+    };
+    const double nR[3] = {-R[0], -R[1], -R[2]}, nU[3] = {-U[0], -U[1], -U[2]};
+    const double D = det3(V, nR, nU);
+    std::vector<int> rect((size_t)t->ngeoms * 4);
+    for (int g = 0; g < t->ngeoms; g++) {
+        int *r = &rect[(size_t)g * 4];
+        r[0] = 0; r[1] = W - 1; r[2] = 0; r[3] = H - 1;                  // x0, x1, y0, y1: the whole frame unless proven smaller
+        const float *b = &t->h_aabb[(size_t)g * 8];
+        bool ok = std::isfinite(D) && std::fabs(D) > 1e-30;
+        double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300, scale = 0.0;
+        for (int k = 0; k < 8 && ok; k++) {
+            const double p[3] = {(double)((k & 1) ? b[4] : b[0]) - c.position[0], (double)((k & 2) ? b[5] : b[1]) - c.position[1],
+                                 (double)((k & 4) ? b[6] : b[2]) - c.position[2]};
+            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { ok = false; break; }
+            const double l = det3(p, nR, nU) / D, lsx = det3(V, p, nU) / D, lsy = det3(V, nR, p) / D;
+            scale = std::max(scale, std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2]));
+            // in front of the eye by a margin relative to the corner's distance (|view| = 1): otherwise the projection is meaningless
+            if (!(l > 1e-6 * (std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2])) && l > 1e-12)) { ok = false; break; }
+            const double x = lsx / l + W * 0.5, y = lsy / l + H * 0.5;
+            xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
+        }
+        if (!ok || !(xlo <= xhi) || !(ylo <= yhi)) continue;
+        // a pixel's rays cover [x - 0.5, x + 0.5] (antialiasing jitter, generateRay); two more pixels for the fp32 ray arithmetic
+        const double m = 2.5;
+        r[0] = (int)std::max(0.0, std::min((double)W, std::floor(xlo - m)));
+        r[1] = (int)std::max(-1.0, std::min((double)W - 1, std::ceil(xhi + m)));
+        r[2] = (int)std::max(0.0, std::min((double)H, std::floor(ylo - m)));
+        r[3] = (int)std::max(-1.0, std::min((double)H - 1, std::ceil(yhi + m)));
+    }
+    std::vector<uint32_t> masks((size_t)t->maxTiles, 0u);
+    auto owned_xy = [&](int i, int &x, int &y) {                        // = owned_pixel (device)
+        const int r = i / W;
+        x = i - r * W;
+        if (t->tm.tile_world <= 1) { y = r; return; }
+        const int k = r / t->tm.tile_rows;
+        y = (k * t->tm.tile_world + t->tm.tile_rank) * t->tm.tile_rows + (r - k * t->tm.tile_rows);
+    };
+    for (int tile = 0; tile < t->maxTiles; tile++) {
+        const int i0 = tile * TILE, i1 = std::min(i0 + TILE, t->tm.owned) - 1;
+        if (i1 < i0) { masks[tile] = 0xffffffffu; continue; }
+        int x0, y0, x1, y1;
+        owned_xy(i0, x0, y0); owned_xy(i1, x1, y1);
+        if (y0 != y1) { x0 = 0; x1 = W - 1; }                            // wraps: whole rows y0 .. y1 (rows of other ranks in between included)
+        uint32_t m = 0;
+        for (int g = 0; g < t->ngeoms; g++) {
+            const int *r = &rect[(size_t)g * 4];
+            if (!(r[1] < x0 || r[0] > x1 || r[3] < y0 || r[2] > y1)) m |= 1u << g;
+        }
+        masks[tile] = m;
+    }
+    HIPCHECK(hipMemcpyAsync(t->d_tile_geoms, masks.data(), sizeof(uint32_t) * masks.size(), hipMemcpyHostToDevice, t->stream));
+    HIPCHECK(hipStreamSynchronize(t->stream));      // (masks is a local)
+    t->tile_geoms_valid = true;
+    return PTX_OK;
+}
+
 int free_tracer(ptx_tracer *t) {
     if (!t) return PTX_OK;
     hipSetDevice(t->device);
     if (t->stream) hipStreamSynchronize(t->stream);
     for (int l = 1; l < MAX_LANES; l++) if (t->lane_stream[l]) hipStreamSynchronize(t->lane_stream[l]);      // work traced ahead
-    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_bvh_wide); hipFree(t->d_bvh_wroot); hipFree(t->d_bvh_wneed); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_ldsblob); hipFree(t->d_texels);
+    hipFree(t->d_geoms); hipFree(t->d_mats); hipFree(t->d_faces); hipFree(t->d_tri9); hipFree(t->d_gtab); hipFree(t->d_aabb); hipFree(t->d_tile_geoms); hipFree(t->d_bvh_nodes); hipFree(t->d_bvh_tris); hipFree(t->d_bvh_root); hipFree(t->d_bvh_depth); hipFree(t->d_bvh_wide); hipFree(t->d_bvh_wroot); hipFree(t->d_bvh_wneed); hipFree(t->d_keys); hipFree(t->d_tile_done); hipFree(t->d_items); hipFree(t->d_item_count); hipFree(t->d_fnorm); hipFree(t->d_cnorm); hipFree(t->d_ldsblob); hipFree(t->d_texels);
     if (t->own_image) hipFree(t->d_image);
     for (int k = 0; k < 3; k++) { hipFree(t->d_fbuf[k]); hipFree(t->d_ibuf[k]); }
     hipFree(t->d_cache_chunk); hipFree(t->d_cache_super);
@@ -1938,6 +2036,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
         bp.fenced = reinterpret_cast<unsigned long long *>(t->d_stats + 65); bp.fence_slots = t->fence_slots;
+        bp.tile_geoms = (first && t->tile_geoms_valid) ? t->d_tile_geoms : nullptr;
         if (t->split_mesh) {
             bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
             bp.items = t->d_items + seg0 * t->seg_items; bp.seg_items = t->seg_items;
@@ -2320,6 +2419,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemcpy(t->d_gtab, hgtab.data(), sizeof(float) * hgtab.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_aabb, sizeof(float) * haabb.size()));
     HC(hipMemcpy(t->d_aabb, haabb.data(), sizeof(float) * haabb.size(), hipMemcpyHostToDevice));
+    t->h_aabb = haabb;
     HC(hipMalloc(&t->d_texels, htex.size()));
     HC(hipMemcpy(t->d_texels, htex.data(), htex.size(), hipMemcpyHostToDevice));
 
@@ -2464,6 +2564,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMalloc(&t->d_stamps, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
     HC(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
 #endif
+    HC(hipMalloc(&t->d_tile_geoms, sizeof(uint32_t) * (size_t)std::max(t->maxTiles, 1)));
+    if (update_tile_geoms(t) != PTX_OK) return fail(PTX_ERR_HIP);
     HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 66));
     HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 66));
     t->fence_slots = (uint32_t)t->cap;
@@ -2499,7 +2601,7 @@ int ptx_set_camera(ptx_tracer *t, const ptx_camera *camera, int trace_depth) {
     camera_to_device(*camera, t->cam);
     t->traceDepth = trace_depth;
     t->cache_valid = false;
-    return PTX_OK;
+    return update_tile_geoms(t);
 }
 
 int ptx_reset_image(ptx_tracer *t) {

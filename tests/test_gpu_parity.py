@@ -663,6 +663,58 @@ def test_scripted_camera_orbit_on_a_live_tracer(gpu_product, O):
             assert beq(T.read_image(), O.image())
 
 
+def test_camera_tile_masks_are_supersets(gpu_product, O, tmp_path, monkeypatch):
+    """Round 4: the camera-ray bounce tests, per tile of 256 pixels, only the geoms whose conservative screen rectangle reaches the
+    tile (host: update_tile_geoms), and tiles that see no geom skip generation, intersection and ranking altogether.  A rectangle that
+    is too small would silently turn hits into misses, so: cameras outside and INSIDE the room, looking along and across walls, eye
+    a hair's breadth from a wall, geoms behind the eye, very narrow and very wide fields of view, frames whose rows are shorter and
+    longer than a tile, a tile split -- every one gives the oracle's image and ray counts, and the image it gives with the masks
+    switched off (PTX_DEBUG_NO_TILE_GEOMS).  The moved camera of a live tracer (ptx_set_camera) gets new masks."""
+    pt = gpu_product
+    import re
+    stock = open(os.path.join(ROOT, "scenes", "cornellObj.txt")).read()
+    assert re.search(r"CAMERA\n(?:.*\n)*?UP[^\n]*\n", stock)
+
+    def with_camera(eye, look, fovy, res):
+        block = "CAMERA\nRES %d %d\nFOVY %g\nITERATIONS 3\nDEPTH 5\nFILE t\nEYE %g %g %g\nLOOKAT %g %g %g\nUP 0 1 0\n" % (tuple(res) + (fovy,) + tuple(eye) + tuple(look))
+        return re.sub(r"CAMERA\n(?:.*\n)*?UP[^\n]*\n", block, stock, count=1)
+    cams = [((0, 5, 10.5), (0, 5, 0), 45, (200, 120)),          # the stock view
+            ((0, 5, 4.0), (0, 5, 0), 70, (300, 37)),            # inside the room, rows longer than a tile
+            ((0.5, 9.6, 0.3), (0.2, 0.0, -0.4), 60, (96, 80)),  # under the light, looking down: geoms behind the eye
+            ((-4.95, 2.0, 0.0), (4.0, 6.0, -1.0), 50, (130, 64)),      # a hair from the left wall, looking across
+            ((0, 5, 30.0), (0, 5, 0), 4, (257, 40)),            # far away, narrow: the room fills the frame
+            ((12.0, 14.0, 14.0), (0, 4, 0), 100, (64, 300)),    # outside, above, very wide; tall frame (rows shorter than a tile)
+            ((0.0, 5.0, -4.9), (0.0, 5.0, 5.0), 65, (150, 90))]        # in front of the back wall, looking OUT of the room
+    for k, (eye, look, fovy, res) in enumerate(cams):
+        s = _scene_from_text(pt, with_camera(eye, look, fovy, res), tmp_path)
+        img = _vs_oracle(pt, O, s, iters=2)
+        with pt.Tracer(s, tile_rows=8, tile_rank=1, tile_world=3) as T:
+            T.render(1, 2)
+            tile_img, tile_rays = T.read_image(), T.stats()["rays_per_bounce"]
+        monkeypatch.setenv("PTX_DEBUG_NO_TILE_GEOMS", "1")
+        try:
+            with pt.Tracer(s) as T:
+                T.render(1, 2)
+                assert beq(T.read_image(), img), k
+            with pt.Tracer(s, tile_rows=8, tile_rank=1, tile_world=3) as T:
+                T.render(1, 2)
+                assert beq(T.read_image(), tile_img) and T.stats()["rays_per_bounce"] == tile_rays, k
+        finally:
+            monkeypatch.delenv("PTX_DEBUG_NO_TILE_GEOMS")
+    # one live tracer walked through all the cameras of one frame size: the masks follow ptx_set_camera
+    s0 = _scene_from_text(pt, with_camera(cams[0][0], cams[0][1], cams[0][2], (160, 100)), tmp_path)
+    with pt.Tracer(s0) as T:
+        for eye, look, fovy, _ in cams:
+            s = _scene_from_text(pt, with_camera(eye, look, fovy, (160, 100)), tmp_path)
+            T.set_camera(s)
+            T.reset_image()
+            T.render(1, 2)
+            got = T.read_image()
+            with pt.Tracer(s) as T2:
+                T2.render(1, 2)
+                assert beq(got, T2.read_image())
+
+
 def test_error_paths(gpu_product):
     pt = gpu_product
     s = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(32, 32), depth=0)

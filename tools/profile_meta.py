@@ -28,6 +28,9 @@ def kernel_label(name):
     m = re.search(r"k_mesh<\s*(true|false)", name) or re.search(r"k_meshILb([01])", name)
     if m:
         return "k_mesh<first>" if m.group(1) in ("true", "1") else "k_mesh"
+    m = re.search(r"k_finish<\s*(true|false)", name) or re.search(r"k_finishILb([01])", name)
+    if m:
+        return "k_finish<first>" if m.group(1) in ("true", "1") else "k_finish"
     for k in ("k_gather", "k_onepass"):
         if k in name:
             return k
