@@ -868,6 +868,21 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             if (tid == 0) run_all[p.sort ? p.sc.nmats - 1 : 0] += min(TILE, n_in - tile * TILE);
             continue;
         }
+        if (FIRST && MODE == 1 && tile_subset == 0u && p.tile_done) {
+            // the same in pass 1 of the split bounce: the tile is "finished in pass 1" (tile_done) with nothing stored; its per-bin counts --
+            // all survivors in the miss bin -- go into the prefix tables as they are, pass 2 folds them into its running prefix
+            int mbin = 0;
+            bool mpend = false;
+            if (alive) classifyRay(hit, ps, pix, mbin, mpend);
+            st_u(stage.idx(), (uint32_t)i << 2, (int32_t)-1);
+            const int missbin = p.sort ? p.sc.nmats - 1 : 0, nalive = min(TILE, n_in - tile * TILE);
+            for (int b = tid; b < nb; b += TILE) {
+                counts_all[(size_t)b * p.maxTiles + tile] = b == missbin ? nalive : 0;
+                counts_scat[(size_t)b * p.maxTiles + tile] = 0;
+            }
+            if (tid == 0) (p.tile_done + (size_t)p.maxTiles * seg)[tile] = 1;
+            continue;
+        }
         {
             Ray ray; ray.o = ps.o; ray.d = ps.d;
             uint32_t mesh_cand = 0;
@@ -1772,11 +1787,21 @@ void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6
 // into (double precision, widened by the antialiasing jitter and two more pixels); a corner at or behind the eye plane makes it the
 // whole frame.  A tile is 256 consecutive OWNED pixels: one span of a row, or -- when it wraps -- whole rows.  Bit g of a tile's
 // word is cleared only when geom g's rectangle misses the tile's: a superset of what any of its rays can hit, so the candidate
-// masks built from it (cullMask<SUBSET>) hold exactly the bits the full loop would set for those rays.  Not with depth of field
-// (rays then start anywhere on the lens), nor where the candidate masks are off; recomputed when the camera changes.
+// masks built from it (cullMask<SUBSET>) hold exactly the bits the full loop would set for those rays.  Recomputed when the camera
+// changes; not where the candidate masks are off.
+// With depth of field (generateRay: src/pathtrace.cu:236-251) a pixel's rays leave a lens -- the eye moved by up to lensRadius 0.8 in
+// WORLD x / y -- towards the pixel's focus point pFocus on the plane z = eye.z +- 11.  A point c is on such a ray iff
+// c = e + mu (pFocus - e), mu = (c.z - eye.z) / (+-11) > 0, i.e. pFocus = centre(c) + l (1 - 1/mu) with centre(c) the perspective
+// image of c on the focus plane and |l| <= 0.8: a disc of radius rho(c) = 0.8 |1 - 1/mu| around it.  Over a box, centre() is a
+// projective map (the hull of the corners' images) and rho is extremal at a corner, so the box's focus points lie within the corners'
+// images widened by the LARGEST corner radius; each is then projected to pixels through the pinhole (the relation between a pixel and
+// its focus point) at the four corners of its bounding square.  Anything doubtful -- a corner not in front of the lens plane, a frame
+// whose pixels do not all look towards the same side of it -- keeps the whole frame.
 int update_tile_geoms(ptx_tracer *t) {
     t->tile_geoms_valid = false;
-    if (!t->cull || t->opt.depth_of_field || t->ngeoms > 32 || t->ngeoms < 1 || getenv("PTX_DEBUG_NO_TILE_GEOMS")) return PTX_OK;
+    if (!t->cull || t->ngeoms > 32 || t->ngeoms < 1 || getenv("PTX_DEBUG_NO_TILE_GEOMS")) return PTX_OK;
+    const bool dof = t->opt.depth_of_field != 0;
+    if (dof && getenv("PTX_DEBUG_NO_TILE_GEOMS_DOF")) return PTX_OK;
     const DCamera &c = t->cam;
     const int W = c.resx, H = c.resy;
     // p - eye = l * (view - R sx - U sy),  R = right * pixelLength.x, U = up * pixelLength.y,  sx = x - W/2, sy = y - H/2  (generateRay)
@@ -1789,23 +1814,58 @@ int update_tile_geoms(ptx_tracer *t) {
     };
     const double nR[3] = {-R[0], -R[1], -R[2]}, nU[3] = {-U[0], -U[1], -U[2]};
     const double D = det3(V, nR, nU);
+    // pixel coordinates of the point eye + p; false: not safely in front of the eye
+    auto project = [&](const double p[3], double &x, double &y) {
+        const double l = det3(p, nR, nU) / D, lsx = det3(V, p, nU) / D, lsy = det3(V, nR, p) / D;
+        // in front of the eye by a margin relative to the point's distance (|view| = 1): otherwise the projection is meaningless
+        if (!(l > 1e-6 * (std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2])) && l > 1e-12)) return false;
+        x = lsx / l + W * 0.5; y = lsy / l + H * 0.5;
+        return std::isfinite(x) && std::isfinite(y);
+    };
+    double zsign = 0.0;                                      // depth of field: the side of the lens plane every pixel looks to
+    bool dof_ok = true;
+    if (dof) {
+        for (int k = 0; k < 4; k++) {                        // the frame's corner pixels (+- the jitter): z of the unnormalised direction
+            const double sx = ((k & 1) ? W + 1.0 : -1.0) - W * 0.5, sy = ((k & 2) ? H + 1.0 : -1.0) - H * 0.5;
+            const double dx = V[0] - R[0] * sx - U[0] * sy, dy = V[1] - R[1] * sx - U[1] * sy, dz = V[2] - R[2] * sx - U[2] * sy;
+            const double z = dz / std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (!(std::fabs(z) > 0.05) || (zsign != 0.0 && (z > 0) != (zsign > 0))) dof_ok = false;
+            zsign = z > 0 ? 1.0 : -1.0;
+        }
+    }
     std::vector<int> rect((size_t)t->ngeoms * 4);
     for (int g = 0; g < t->ngeoms; g++) {
         int *r = &rect[(size_t)g * 4];
         r[0] = 0; r[1] = W - 1; r[2] = 0; r[3] = H - 1;                  // x0, x1, y0, y1: the whole frame unless proven smaller
         const float *b = &t->h_aabb[(size_t)g * 8];
-        bool ok = std::isfinite(D) && std::fabs(D) > 1e-30;
-        double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300, scale = 0.0;
+        bool ok = std::isfinite(D) && std::fabs(D) > 1e-30 && dof_ok;
+        double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+        double cp[8][3], rho = 0.0;
         for (int k = 0; k < 8 && ok; k++) {
-            const double p[3] = {(double)((k & 1) ? b[4] : b[0]) - c.position[0], (double)((k & 2) ? b[5] : b[1]) - c.position[1],
-                                 (double)((k & 4) ? b[6] : b[2]) - c.position[2]};
-            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { ok = false; break; }
-            const double l = det3(p, nR, nU) / D, lsx = det3(V, p, nU) / D, lsy = det3(V, nR, p) / D;
-            scale = std::max(scale, std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2]));
-            // in front of the eye by a margin relative to the corner's distance (|view| = 1): otherwise the projection is meaningless
-            if (!(l > 1e-6 * (std::fabs(p[0]) + std::fabs(p[1]) + std::fabs(p[2])) && l > 1e-12)) { ok = false; break; }
-            const double x = lsx / l + W * 0.5, y = lsy / l + H * 0.5;
-            xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
+            cp[k][0] = (double)((k & 1) ? b[4] : b[0]) - c.position[0]; cp[k][1] = (double)((k & 2) ? b[5] : b[1]) - c.position[1];
+            cp[k][2] = (double)((k & 4) ? b[6] : b[2]) - c.position[2];
+            if (!std::isfinite(cp[k][0]) || !std::isfinite(cp[k][1]) || !std::isfinite(cp[k][2])) ok = false;
+            if (ok && dof) {
+                const double mu = cp[k][2] / (zsign * 11.0);             // focalDistance 11 (src/pathtrace.cu:238)
+                if (!(mu > 1e-3)) { ok = false; break; }                 // not in front of the lens plane: no bound from this corner
+                rho = std::max(rho, 0.8 * std::fabs(1.0 - 1.0 / mu) * 1.0001 + 1e-6);      // lensRadius .8 (:237)
+            }
+        }
+        for (int k = 0; k < 8 && ok; k++) {
+            if (!dof) {
+                double x, y;
+                if (!project(cp[k], x, y)) { ok = false; break; }
+                xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
+                continue;
+            }
+            const double mu = cp[k][2] / (zsign * 11.0);
+            const double fx = cp[k][0] / mu, fy = cp[k][1] / mu;         // the corner's image on the focus plane (relative to the eye)
+            for (int q = 0; q < 4 && ok; q++) {
+                const double p[3] = {fx + ((q & 1) ? rho : -rho), fy + ((q & 2) ? rho : -rho), zsign * 11.0};
+                double x, y;
+                if (!project(p, x, y)) { ok = false; break; }
+                xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
+            }
         }
         if (!ok || !(xlo <= xhi) || !(ylo <= yhi)) continue;
         // a pixel's rays cover [x - 0.5, x + 0.5] (antialiasing jitter, generateRay); two more pixels for the fp32 ray arithmetic

@@ -688,6 +688,9 @@ def test_camera_tile_masks_are_supersets(gpu_product, O, tmp_path, monkeypatch):
     for k, (eye, look, fovy, res) in enumerate(cams):
         s = _scene_from_text(pt, with_camera(eye, look, fovy, res), tmp_path)
         img = _vs_oracle(pt, O, s, iters=2)
+        # depth of field: rays leave a lens of radius 0.8 in world x / y towards focus points 11 away in z -- the rectangles are then
+        # those of the geoms' focus-plane images widened by the lens (update_tile_geoms); cameras that do not look along z keep all geoms
+        img_dof = _vs_oracle(pt, O, s, iters=2, depth_of_field=1)
         with pt.Tracer(s, tile_rows=8, tile_rank=1, tile_world=3) as T:
             T.render(1, 2)
             tile_img, tile_rays = T.read_image(), T.stats()["rays_per_bounce"]
@@ -696,11 +699,19 @@ def test_camera_tile_masks_are_supersets(gpu_product, O, tmp_path, monkeypatch):
             with pt.Tracer(s) as T:
                 T.render(1, 2)
                 assert beq(T.read_image(), img), k
+            with pt.Tracer(s, depth_of_field=1) as T:
+                T.render(1, 2)
+                assert beq(T.read_image(), img_dof), k
             with pt.Tracer(s, tile_rows=8, tile_rank=1, tile_world=3) as T:
                 T.render(1, 2)
                 assert beq(T.read_image(), tile_img) and T.stats()["rays_per_bounce"] == tile_rays, k
         finally:
             monkeypatch.delenv("PTX_DEBUG_NO_TILE_GEOMS")
+    # the spaceship scene (split mesh search: tiles without a geom skip generation and intersection in pass 1) with depth of field
+    ship = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship.txt"), res=(320, 180), depth=5)
+    ship.apply_runcuda_camera()
+    _vs_oracle(pt, O, ship, iters=2, depth_of_field=1)
+    _vs_oracle(pt, O, ship, iters=2)
     # one live tracer walked through all the cameras of one frame size: the masks follow ptx_set_camera
     s0 = _scene_from_text(pt, with_camera(cams[0][0], cams[0][1], cams[0][2], (160, 100)), tmp_path)
     with pt.Tracer(s0) as T:
