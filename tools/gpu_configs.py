@@ -11,8 +11,8 @@ CASES = [
     ("C2-aa", "cornell.txt", (800, 800), 8, {}, 512),
     ("C3", "cornellGlass.txt", (1920, 1080), 12, {}, 192),
     ("C4", "cornellObj.txt", (1920, 1080), 8, {}, 192),
-    ("C5-320", "cornellSpaceship.txt", (3840, 2160), 8, dict(depth_of_field=1), 32),
-    ("C5-20k", "cornellSpaceship20k.txt", (3840, 2160), 8, dict(depth_of_field=1), 32),
+    ("C5-320", "cornellSpaceship.txt", (3840, 2160), 8, dict(depth_of_field=1), 72),
+    ("C5-20k", "cornellSpaceship20k.txt", (3840, 2160), 8, dict(depth_of_field=1), 72),
 ]
 for tag, scene, res, depth, opt, iters in CASES:
     s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=res, depth=depth); s.apply_runcuda_camera()
