@@ -247,6 +247,10 @@ int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void
 int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44);             /* all W*H camera rays */
 int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *cos_out,
                  const double *pw_in, double *pow5_out, const float *powf_xy, float *powf_out);
+/* The device's guarded core square root / reciprocal (pt_device.h: pt_sqrt, pt_rsqrt_glm, pt_rcp_pos) against the compiler's IEEE
+ * expansions of sqrtf(x), 1 / sqrtf(x) and 1 / a, on ALL 2^32 operand bit patterns: mismatches[3] = how many patterns differ
+ * bitwise (two NaNs count as equal).  0, 0, 0 is the only acceptable answer. */
+int ptx_kat_fast_exact(ptx_tracer *t, int64_t mismatches[3]);
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */

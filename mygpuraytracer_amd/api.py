@@ -176,6 +176,8 @@ def load_library():
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
     L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
     L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "ptx_kat_fast_exact"):        # (absent from the older builds the A/B scripts load through PTX_AB_LIBRARY)
+        L.ptx_kat_fast_exact.restype, L.ptx_kat_fast_exact.argtypes = i, [vp, vp]
     L.ptx_debug_set_capture.restype, L.ptx_debug_set_capture.argtypes = i, [vp, i]
     L.ptx_debug_read_stream.restype, L.ptx_debug_read_stream.argtypes = i, [vp, C.POINTER(i), vp, vp, vp, vp, i]
     # several devices behind one handle (csrc/pt_multi.cpp)
@@ -602,6 +604,12 @@ class Tracer:
         _check(self.lib.ptx_get_kernel_times(self.h, _ptr(ms), _ptr(n)), "ptx_get_kernel_times")
         names = ("k_bounce<first>", "k_bounce", "k_mesh", "k_bounce pass2")      # (split mesh search: the first two are then its pass 1)
         return {nm: (float(ms[k]), int(n[k])) for k, nm in enumerate(names)}
+
+    def kat_fast_exact(self):
+        """mismatches of the device's guarded core sqrt / 1/sqrt / 1/a against the compiler's IEEE expansions over all 2^32 operands"""
+        m = np.zeros(3, np.int64)
+        _check(self.lib.ptx_kat_fast_exact(self.h, _ptr(m)), "ptx_kat_fast_exact")
+        return m.tolist()
 
     def owned_pixels(self):
         return self.lib.ptx_owned_pixels(self.h)

@@ -31,9 +31,57 @@ PT_HD vec3 neg(vec3 a) { return V3(-a.x, -a.y, -a.z); }
 PT_HD float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // glm cross (func_geometric.inl:134-141)
 PT_HD vec3 cross(vec3 x, vec3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+// ---- correctly rounded square root and reciprocal without their range handling (device, round 4) ------------------------------
+// `__builtin_sqrtf` and `1.0f / x` are IEEE-exact here (hipcc's correctly-rounded-divide-sqrt default), and on gfx950 the compiler expands
+// each into a CORE -- v_sqrt_f32 and a one-ulp correction by two fused residuals; v_rcp_f32, one Newton step, three residual steps --
+// wrapped in range handling: operands below 2^-96 are scaled up and the result down (v_cmp, v_mul, v_cndmask, ..., 16 instructions
+// for a root where the core is 9), v_div_scale / v_div_fmas / v_div_fixup around a quotient (11 where the core is 6).  The path
+// tracer's roots and reciprocals -- a normalize per transformed direction, a length per hit, 1/a per triangle: every seventh vector
+// instruction of k_bounce -- see operands in the normal range practically always.  These two functions run THE SAME CORE, instruction
+// for instruction as the compiler emits it (v_sqrt / v_rcp are deterministic, the fused steps are IEEE operations), behind one
+// unsigned compare on the operand's bits, and hand everything else -- zero, subnormal, tiny, infinite, NaN, negative -- to the
+// compiler's own expansion.  Same result for every operand by construction; `ptx_kat_fast_exact` compares them with the built-ins on
+// the device over every exponent and on random operands (tests/test_gpu_parity.py), and every parity test runs on top of them.
+#ifndef PT_FAST_EXACT
+#define PT_FAST_EXACT 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PT_FAST_EXACT
+// 2^-96 <= x < +inf as ONE unsigned compare on the bits (negative, zero, subnormal, tiny, inf and NaN fail it)
+__device__ __forceinline__ bool pt_in_core_range(float x) { return __float_as_uint(x) - 0x0f800000u < 0x70000000u; }
+__device__ __forceinline__ float pt_sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);                                    // within one ulp
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r1 = __builtin_fmaf(-sm, s, x);
+    const float s1 = 0.0f >= r1 ? sm : s;
+    const float r2 = __builtin_fmaf(-sp, s, x);
+    return 0.0f < r2 ? sp : s1;
+}
+// 1 / t for 2^-48 <= t < 2^64 (a root of an operand that passed pt_in_core_range): the quotient's core with numerator 1
+__device__ __forceinline__ float pt_rcp_core(float t) {
+    float r = __builtin_amdgcn_rcpf(t);
+    const float e = __builtin_fmaf(-t, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;                                                                  // (= 1.0f * r)
+    const float e2 = __builtin_fmaf(-t, q, 1.0f);
+    q = __builtin_fmaf(e2, r, q);
+    const float e3 = __builtin_fmaf(-t, q, 1.0f);
+    return __builtin_fmaf(e3, r, q);
+}
+__device__ __forceinline__ float pt_sqrt(float x) { return __builtin_expect(pt_in_core_range(x), 1) ? pt_sqrt_core(x) : __builtin_sqrtf(x); }
+__device__ __forceinline__ float pt_rsqrt_glm(float x) {                           // glm inversesqrt: 1 / sqrt(x), two roundings
+    if (__builtin_expect(pt_in_core_range(x), 1)) return pt_rcp_core(pt_sqrt_core(x));
+    return 1.0f / __builtin_sqrtf(x);
+}
+// 1 / a for FLT_EPSILON <= a (the caller's own test) and a < 2^60: in range for the core; anything larger takes the division
+__device__ __forceinline__ float pt_rcp_pos(float a) { return __builtin_expect(a < 1.152921504606846976e18f, 1) ? pt_rcp_core(a) : 1.0f / a; }
+#else
+PT_HD float pt_sqrt(float x) { return __builtin_sqrtf(x); }
+PT_HD float pt_rsqrt_glm(float x) { return 1.0f / __builtin_sqrtf(x); }
+PT_HD float pt_rcp_pos(float a) { return 1.0f / a; }
+#endif
 // glm normalize = x * (1 / sqrt(dot(x,x)))  (func_geometric.inl:154-159, func_exponential.inl:62-68)
-PT_HD vec3 normalize(vec3 a) { return scale(a, 1.0f / __builtin_sqrtf(dot(a, a))); }
-PT_HD float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
+PT_HD vec3 normalize(vec3 a) { return scale(a, pt_rsqrt_glm(dot(a, a))); }
+PT_HD float length(vec3 a) { return pt_sqrt(dot(a, a)); }
 PT_HD float fmin_glm(float x, float y) { return x < y ? x : y; }   // glm min: x < y ? x : y
 PT_HD float fmax_glm(float x, float y) { return x > y ? x : y; }   // glm max: x > y ? x : y
 
@@ -407,7 +455,7 @@ PT_DEV float sphereTestCore(const DGeom &sphere, Ray r, Cand &c) {
     float vDotDirection = dot(rt.o, rt.d);
     float radicand = vDotDirection * vDotDirection - (dot(rt.o, rt.o) - radius * radius);   // powf(.5f,2) == .25f
     if (radicand < 0) return -1.f;
-    float squareRoot = __builtin_sqrtf(radicand);
+    float squareRoot = pt_sqrt(radicand);
     float firstTerm = -vDotDirection;
     float t1 = firstTerm + squareRoot;
     float t2 = firstTerm - squareRoot;
@@ -452,7 +500,7 @@ PT_HD bool rayTriangle(vec3 orig, vec3 dir, vec3 v0, vec3 e1, vec3 e2, float &bx
     vec3 p = cross(dir, e2);
     float a = dot(e1, p);
     if (a < 1.1920928955078125e-07f) return false;     // FLT_EPSILON
-    float f = 1.0f / a;
+    float f = pt_rcp_pos(a);                           // (a >= FLT_EPSILON here)
     vec3 s = sub(orig, v0);
     bx = f * dot(s, p);
     if (bx < 0.0f) return false;
@@ -1031,7 +1079,7 @@ PT_DEV unsigned long long primKey(const float *gtab, int g, Ray ray) {
         float vDotDirection = dot(q.o, q.d);
         float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
         if (!(radicand < 0)) {
-            float squareRoot = __builtin_sqrtf(radicand);
+            float squareRoot = pt_sqrt(radicand);
             float firstTerm = -vDotDirection;
             float t1 = firstTerm + squareRoot;
             float t2 = firstTerm - squareRoot;
@@ -1202,7 +1250,7 @@ PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long ke
             const float radius = .5f;
             float vDotDirection = dot(q.o, q.d);
             float radicand = vDotDirection * vDotDirection - (dot(q.o, q.o) - radius * radius);
-            float squareRoot = __builtin_sqrtf(radicand);
+            float squareRoot = pt_sqrt(radicand);
             float firstTerm = -vDotDirection;
             float t1 = firstTerm + squareRoot;
             float t2 = firstTerm - squareRoot;
@@ -1251,8 +1299,8 @@ PT_DEV float meshIntersectionTest(const DScene &sc, const DGeom &g, Ray r, vec3 
 
 // calculateRandomDirectionInHemisphere, src/interactions.h:11-43
 PT_DEV vec3 randomDirectionInHemisphere(vec3 normal, Rng &rng) {
-    float up = __builtin_sqrtf(rng.uniform(0.f, 1.f));
-    float over = __builtin_sqrtf(1 - up * up);
+    float up = pt_sqrt(rng.uniform(0.f, 1.f));
+    float over = pt_sqrt(1 - up * up);
     float around = rng.uniform(0.f, 1.f) * PT_TWO_PI;
     vec3 notNormal;
     if (__builtin_fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) notNormal = V3(1, 0, 0);
@@ -1274,7 +1322,7 @@ PT_DEV vec3 reflect(vec3 I, vec3 N) { return sub(I, scale(scale(N, dot(N, I)), 2
 PT_DEV vec3 refract(vec3 I, vec3 N, float eta) {
     float dotValue = dot(N, I);
     float k = 1.0f - eta * eta * (1.0f - dotValue * dotValue);
-    float f = eta * dotValue + __builtin_sqrtf(k);
+    float f = eta * dotValue + pt_sqrt(k);
     vec3 r = sub(scale(I, eta), scale(N, f));
     return scale(r, (float)(k >= 0.0f));
 }

@@ -1620,6 +1620,28 @@ __global__ void k_kat_libm(int n, const float *x, float *s, float *c, const doub
     pout[i] = powf_own(pxy[2 * i], pxy[2 * i + 1]);
 }
 
+// every float bit pattern through the guarded core routines and through the compiler's own expansions
+__global__ void k_kat_fast_exact(unsigned long long *mism) {
+    unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    const unsigned long long total = 1ull << 32, step = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += step) {
+        float x = __uint_as_float((uint32_t)k);
+        asm volatile("" : "+v"(x));                          // (the two sides must not be merged into one computation)
+        float y = x;
+        asm volatile("" : "+v"(y));
+        const float a0 = pt_sqrt(x), b0 = __builtin_sqrtf(y);
+        const float a1 = pt_rsqrt_glm(x), b1 = 1.0f / __builtin_sqrtf(y);
+        // pt_rcp_pos is only ever called with a >= FLT_EPSILON (or NaN): the patterns below that are the caller's business
+        const bool dom = !(x < 1.1920928955078125e-07f);
+        const float a2 = dom ? pt_rcp_pos(x) : 0.f, b2 = dom ? 1.0f / y : 0.f;
+        auto same = [](float p, float q) { return __float_as_uint(p) == __float_as_uint(q) || (p != p && q != q); };
+        m0 += same(a0, b0) ? 0 : 1; m1 += same(a1, b1) ? 0 : 1; m2 += same(a2, b2) ? 0 : 1;
+    }
+    if (m0) atomicAdd(&mism[0], m0);
+    if (m1) atomicAdd(&mism[1], m1);
+    if (m2) atomicAdd(&mism[2], m2);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3027,6 +3049,21 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
     HIPCHECK(hipMemcpy(cos_out, dc, 4 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(pow5_out, dp5, 8 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(powf_out, dpo, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_kat_fast_exact(ptx_tracer *t, int64_t mismatches[3]) {
+    KAT_PROLOGUE
+    if (!mismatches) return set_error(PTX_ERR_INVALID, "null argument");
+    DevBuf<unsigned long long> d;
+    HIPCHECK(hipMalloc(&d.p, 3 * sizeof(unsigned long long)));
+    HIPCHECK(hipMemsetAsync(d.p, 0, 3 * sizeof(unsigned long long), t->stream));
+    hipLaunchKernelGGL(k_kat_fast_exact, dim3(t->cus * 8), dim3(256), 0, t->stream, d.p);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    unsigned long long h[3];
+    HIPCHECK(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) mismatches[k] = (int64_t)h[k];
     return PTX_OK;
 }
 

@@ -99,6 +99,17 @@ def test_device_libm_bit_identical(gpu_product, O):
     T.close()
 
 
+def test_core_sqrt_and_reciprocal_equal_the_ieee_expansions_on_every_operand(gpu_product):
+    """pt_device.h (round 4): sqrtf, 1 / sqrtf and the triangle test's 1 / a run the CORE of the compiler's correctly rounded
+    expansions behind one range compare and leave every other operand to the expansion itself.  All 2^32 bit patterns through both, on
+    the device: not one differs (NaNs compare as equal).  (The kernels' parity with the oracle rests on these being IEEE results.)"""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(32, 32), depth=2)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s) as T:
+        assert T.kat_fast_exact() == [0, 0, 0]
+
+
 @pytest.mark.parametrize("scene", ["cornellGlass", "cornellObj", "cornellSpaceship"])
 def test_intersection_kats_on_device(gpu_product, O, scene):
     """The golden per-geom vectors (produced by the reference's own box/sphere/mesh tests) through the device functions."""
