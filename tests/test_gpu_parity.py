@@ -1240,6 +1240,44 @@ def test_random_scenes_on_the_tile_path(gpu_product, O, tmp_path, seed):
     _vs_oracle(gpu_product, O, s, iters=2, no_cull=1, batch=1)
 
 
+@pytest.mark.parametrize("seed", _fuzz_seeds())
+def test_random_cameras_see_what_the_oracle_sees(gpu_product, O, tmp_path, seed):
+    """Fuzz of the camera-dependent host work (round 4: per-tile geom masks from projected boxes, with and without the lens model):
+    a random eye -- inside the lit box, outside it, sometimes a few centimetres from a wall or inside an object's box -- looking at a
+    random point with a random field of view at a random frame size, over a handful of random objects.  Image and rays per bounce
+    equal the oracle's, with and without depth of field."""
+    rng = np.random.default_rng(5000 + seed)
+    mats = [(1, 1, 1, 0, 0, 0, 0, 0, 0, 5), (.9, .9, .9, 0, 0, 0, 0, 0, 0, 0), (.8, .3, .3, 0, 0, 0, 0, 0, 0, 0),
+            (.3, .8, .3, 0, 0, 0, 0, 0, 0, 0), (.95, .95, .95, .95, .95, .95, 1, 0, 0, 0), (.95, .95, .95, .8, .85, .95, 0, 1, 1.5, 0)]
+    text = "".join(MAT % ((m,) + mats[m]) for m in range(len(mats)))
+    W, H = int(rng.integers(40, 400)), int(rng.integers(24, 160))
+    if rng.random() < 0.5:
+        eye = rng.uniform([-4.8, 0.2, -4.8], [4.8, 9.6, 4.8])                 # inside the room
+    else:
+        eye = rng.uniform([-12, -2, 6], [12, 14, 25])                         # outside, in front of the open side
+    if rng.random() < 0.25:
+        eye[int(rng.integers(0, 3))] = [(-4.97, 4.97), (0.03, 9.8), (-4.97, 4.97)][int(rng.integers(0, 3))][int(rng.integers(0, 2))]
+    look = rng.uniform([-5, 0, -5], [5, 10, 5])
+    fovy = float(rng.choice([3.0, 20.0, 45.0, 75.0, 110.0]))
+    text += ("CAMERA\nRES %d %d\nFOVY %g\nITERATIONS 10\nDEPTH 6\nFILE fuzz\nEYE %g %g %g\nLOOKAT %g %g %g\nUP 0 1 0\n\n"
+             % ((W, H, fovy) + tuple(eye) + tuple(look)))
+    objs = ["cube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 4 .3 4", "cube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 11 .01 11",
+            "cube\nmaterial 1\nTRANS 0 10 0\nROTAT 0 0 90\nSCALE .01 11 11", "cube\nmaterial 1\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 11 11",
+            "cube\nmaterial 2\nTRANS -5 5 0\nROTAT 0 0 0\nSCALE .01 11 11", "cube\nmaterial 3\nTRANS 5 5 0\nROTAT 0 0 0\nSCALE .01 11 11"]
+    for k in range(int(rng.integers(2, 8))):
+        pos = rng.uniform([-3.5, 1.0, -3.5], [3.5, 8.0, 3.0])
+        rot = rng.uniform(-180, 180, 3)
+        sc = rng.uniform(0.4, 2.5, 3)
+        kind = int(rng.integers(0, 4))
+        head = "obj\n../models/cube.obj" if kind == 0 else ("obj\n../models/standin_ship.obj" if kind == 3 and k == 0
+                                                            else ("sphere" if kind == 1 else "cube") + "\nmaterial %d" % int(rng.integers(1, len(mats))))
+        objs.append(head + "\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g" % (tuple(pos) + tuple(rot) + tuple(sc)))
+    text += "".join("OBJECT %d\n%s\n\n" % (i, o) for i, o in enumerate(objs))
+    s = _scene_from_text(gpu_product, text, tmp_path)
+    _vs_oracle(gpu_product, O, s, iters=2)
+    _vs_oracle(gpu_product, O, s, iters=2, depth_of_field=1)
+
+
 def test_split_mesh_search_with_many_meshes_per_ray(gpu_product, O, tmp_path):
     """Five BVH meshes (the stand-in ship, overlapping boxes) and three small ones without a tree among 22 geoms: the split mesh
     search parks a ray once, whatever the number of meshes whose boxes it reaches (a bit per geom; rounds 1-2 handled two
