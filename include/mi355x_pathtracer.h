@@ -227,8 +227,8 @@ int ptx_pin_host_buffer(void *p, size_t bytes);
 int ptx_unpin_host_buffer(void *p);
 
 /* Optional per-kernel device timing (hipEvents on the tracer's stream around every launch while on).
- * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh (split mesh search only: search + finishing of the
- * parked rays), 3 = pass 2 of the split bounce (the ranking pass after k_mesh, first and later bounces; 0 for scenes without the split: kinds 0 / 1 are then the whole bounce,
+ * kinds: 0 = k_bounce<first> (ray generation + intersect), 1 = k_bounce (shade + intersect), 2 = k_mesh + k_finish (split mesh search only: the search of the parked rays' meshes and their
+ * finishing, one bracket around both launches), 3 = pass 2 of the split bounce (the ranking pass after k_mesh, first and later bounces; 0 for scenes without the split: kinds 0 / 1 are then the whole bounce,
  * with the split they are its pass 1).
  * ptx_get_kernel_times returns the sums since it was last called and clears them. */
 int ptx_set_kernel_timing(ptx_tracer *t, int on);

@@ -29,7 +29,8 @@
 //    (blockIdx.y), and three such batches are in flight on three streams so that their kernels fill each other's tails.
 //  * Intersection is tile-cooperative (tileIntersect): candidate masks from conservative world boxes, the (ray, geom)
 //    pairs of a 256-path tile pooled in LDS and worked off by dense waves with a 64-bit LDS minimum per ray.  Scenes
-//    with BVH meshes run the mesh search as a kernel of its own (k_mesh) between two halves of k_bounce.
+//    with BVH meshes run the mesh search as kernels of their own (k_mesh: the search, refilling waves; k_finish: the parked rays'
+//    finishing) between two halves of k_bounce.
 //  * Scene tables (materials, per-geom matrices, small meshes' triangles, tabulated normals) are staged in LDS; the
 //    world boxes are read through the scalar cache.
 #include <hip/hip_runtime.h>
@@ -452,8 +453,8 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     TI_STAMP(7);
 }
 
-// What pass 1 of the split bounce (and k_mesh, for the rays pass 1 parked) tells pass 2 about ray i: one word, lsrc[i] of the stage
-// until the tail overwrites it.  CAND = parked with mesh candidates in slot (bits 16-23) of its tile, k_mesh will replace the
+// What pass 1 of the split bounce (and k_finish, for the rays pass 1 parked) tells pass 2 about ray i: one word, lsrc[i] of the stage
+// until the tail overwrites it.  CAND = parked with mesh candidates in slot (bits 16-23) of its tile, k_finish will replace the
 // word; otherwise the ray is finished -- alive / stored flags, its bin (bits 0-15) and, if stored, the slot its record lies in.
 constexpr int32_t K1_CAND = (int32_t)0x80000000u, K1_ALIVE = 0x40000000, K1_PEND = 0x20000000;
 
@@ -599,7 +600,7 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // chain of dependent node visits -- does not hold the tile's other waves at a barrier: MODE 1 does the whole bounce for the
 // rays that reach no mesh's box and, for the others, everything up to the best hit among cubes and spheres; those it parks
 // (origin, direction, colour, pixel, candidate mask in a stage slot at the top of the tile, the key in `keys`) with one queue
-// entry each; k_mesh walks the queue with one lane per parked ray in dense, lean waves, searches its meshes and finishes it;
+// entry each; k_mesh's waves draw rays from the queue and search their meshes, k_finish finishes them, one dense lane per ray;
 // MODE 2 ranks all rays of the tile (the order needs every ray's bin) and writes the sort keys.  Same arithmetic, same bits.
 // FAST: the options that are run-time values in the general kernel are compile-time constants for the common case -- no
 // textures, material sort on, candidate masks and all scene tables in LDS, no BVH mesh, no bump map, no depth
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (MODE == 1 && tid == 0) *ccnt = 0;           // (first touched after tileIntersect's barriers)
         if (MODE == 2) {                 // pass 1 left one word per ray; only the rays with mesh candidates were parked
             alive = false;
-            // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_mesh)
+            // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
             if (i < n_in) {
                 if (FIRST) k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
                 myslot = (k1 >> 16) & 0xff;
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 // ranked and sorted by bin among its like, record written to the bottom of the tile; pass 2 gets ONE word about it
                 // (round 3; rounds 1-2 parked every ray: 48 B out and 48 B back in for each, which is what bounded the two passes).
                 // What pass 2 still does for all is the ranking that defines the order: it needs every ray's bin, and the
-                // candidates' are not known before k_mesh.
+                // candidates' are not known before k_mesh / k_finish.
                 pass1_partial = true;
                 {
                     const bool is_cand = mesh_cand != 0u;                        // (implies alive)
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                         stage.dx()[sa] = ray.d.x; stage.dy()[sa] = ray.d.y; stage.dz()[sa] = ray.d.z;
                         stage.cr()[sa] = ps.color.x; stage.cg()[sa] = ps.color.y; stage.cb()[sa] = ps.color.z;
                         stage.pix()[sa] = pix;
-                        stage.mg()[sa] = i;                                      // whose ray this is: k_mesh writes the verdict to lsrc[i]
+                        stage.mg()[sa] = i;                                      // whose ray this is: k_finish writes the verdict to lsrc[i]
                         stage.nx()[sa] = __int_as_float((int)mesh_cand);         // the meshes whose boxes it reaches (bit per geom)
                         (p.keys + p.seg_keys * seg)[sa] = key;
                         k1 = K1_CAND | (myslot << 16);
@@ -1683,7 +1684,7 @@ struct ptx_tracer {
     float *d_fnorm = nullptr, *d_cnorm = nullptr;        // precomputed normals (DScene::fnorm / cnorm)
     float *d_ldsblob = nullptr;                          // DScene::ldsblob for the ntri_lds k_bounce is launched with
     uint32_t bump_bits = 0;
-    bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + MODE 2 (scenes with BVH meshes)
+    bool split_mesh = false;                             // k_bounce as MODE 1 + k_mesh + k_finish + MODE 2 (scenes with BVH meshes)
     bool no_fast = false;                                // PTX_DEBUG_NO_FAST: always the general k_bounce (A/B timing, tests of both variants)
     bool force_fast = false;                             // PTX_DEBUG_FORCE_FAST: ask for the specialised variant at every launch (refused
                                                          // with PTX_ERR_INVALID where its preconditions do not hold; tests only)
@@ -1726,7 +1727,7 @@ struct ptx_tracer {
     // optional per-kernel timing (bench.py's roofline leg): events around every launch of an iteration
     bool ktiming = false;
     std::vector<hipEvent_t> kev;                         // pairs (start, stop)
-    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh, 3 pass 2 of the split bounce (the ranking pass)
+    std::vector<int> kev_kind;                           // per pair: 0 k_bounce<first>, 1 k_bounce, 2 k_mesh + k_finish, 3 pass 2 of the split bounce (the ranking pass)
     size_t kev_used = 0;
     // debug capture
     int capture_bounce = -1;

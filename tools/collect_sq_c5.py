@@ -12,7 +12,8 @@ from profile_meta import kernel_label, source_sha16, how_of
 
 def main(tag):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_c5_%s_a" % tag, "**", "*_counter_collection.csv"), recursive=True):
+    # (gpurun_out/ keeps earlier calls' files too -- other process ids in the names: only the newest pass counts)
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_c5_%s_a" % tag, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             lab = kernel_label(r["Kernel_Name"])
             if lab:
