@@ -582,6 +582,9 @@ __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, i
 #ifndef PT_QCAP
 #define PT_QCAP (4 * TILE)
 #endif
+#ifndef PT_RANK_SLICED
+#define PT_RANK_SLICED 1       // later bounces, <= 16 bins: the in-wave ranking bit-sliced instead of one pass per bin that occurs
+#endif
 constexpr int QCAP = PT_QCAP;                        // LDS queue entries of MODE 1, behind the record buffer, + its two counters
 constexpr int QUEUE_WORDS = QCAP + 4;
 // MODE 1: LDS queue -> global queue of the segment (all threads of the workgroup; uniform call)
@@ -986,7 +989,32 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             // vector instructions per bin that occurs in the wave instead of 28.  (Visiting EVERY bin in turn instead -- no readlane,
             // no find-first -- is 13 per bin and loses: camera rays see two or three of the eight bins.)
             const int abin = alive ? bin : -1, pbin = pending ? bin : -1;
-            {
+            if (PT_RANK_SLICED && MODE != 2 && !FIRST && nb <= 16) {
+                // Up to 16 bins, later bounces (a wave of scattered rays sees four or five of the bins): bit-sliced.  Four ballots give the
+                // lanes whose bin has bit k set; a lane ANDs together, per bit of its OWN bin, that mask or its complement -- the lanes of
+                // its bin, as a 64-bit value of its own -- and ranks itself with v_mbcnt on it: ~30 vector instructions whatever the number
+                // of bins, where the loop below costs ~15 per bin that occurs.  (Camera rays see two or three bins: they keep the loop.)
+                const unsigned long long A = __builtin_amdgcn_uicmp((uint32_t)abin, 0xffffffffu, 33), P = __builtin_amdgcn_uicmp((uint32_t)pbin, 0xffffffffu, 33);
+                uint32_t slo = 0xffffffffu, shi = 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k && (nb - 1) >> k == 0) break;                       // (uniform: bins below 2^k need no more bits)
+                    const unsigned long long Bk = __builtin_amdgcn_uicmp((uint32_t)bin & (1u << k), 0u, 33);
+                    const bool set = (bin >> k) & 1;
+                    slo &= set ? (uint32_t)Bk : ~(uint32_t)Bk;
+                    shi &= set ? (uint32_t)(Bk >> 32) : ~(uint32_t)(Bk >> 32);
+                }
+                const uint32_t alo = slo & (uint32_t)A, ahi = shi & (uint32_t)(A >> 32), plo = slo & (uint32_t)P, phi = shi & (uint32_t)(P >> 32);
+                const int ra = (int)__builtin_amdgcn_mbcnt_hi(ahi, __builtin_amdgcn_mbcnt_lo(alo, 0u));
+                const int rs = (int)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                if (alive) {
+                    r_all = ra; r_scat = rs;
+                    if (ra == 0) {                                              // the first lane of its bin in this wave: the wave's counts
+                        w_all[wave * nb + bin] = __popc(alo) + __popc(ahi);
+                        w_scat[wave * nb + bin] = __popc(plo) + __popc(phi);
+                    }
+                }
+            } else {
                 unsigned long long remaining = __builtin_amdgcn_uicmp((uint32_t)abin, 0xffffffffu, 33);       // (alive lanes)
                 while (remaining) {
                     int leader = __ffsll((long long)remaining) - 1;
