@@ -251,6 +251,11 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
  * expansions of sqrtf(x), 1 / sqrtf(x) and 1 / a, on ALL 2^32 operand bit patterns: mismatches[3] = how many patterns differ
  * bitwise (two NaNs count as equal).  0, 0, 0 is the only acceptable answer. */
 int ptx_kat_fast_exact(ptx_tracer *t, int64_t mismatches[3]);
+/* CPU-only (no device, no tracer): the per-tile geom masks the camera-ray bounce uses (bit g of masks_out[tile] clear = no camera ray of
+ * that tile of 256 owned pixels can reach box g; boxes6 = lo xyz, hi xyz per geom, <= 32 geoms), for a camera, depth of field on / off and a
+ * row-tile split.  Returns the number of tiles, -1 on a bad argument.  The CPU tests check the superset property ray by ray. */
+int ptx_debug_tile_geoms(const ptx_camera *camera, int ngeoms, const float *boxes6, int depth_of_field, int tile_rows, int tile_rank,
+                         int tile_world, uint32_t *masks_out, int max_tiles);
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */

@@ -73,6 +73,21 @@ class Stats(C.Structure):
                 ("loop_ms_total", C.c_double), ("iterations", C.c_int64), ("fenced", C.c_int64)]
 
 
+def debug_tile_geoms(camera, boxes6, depth_of_field=False, tile=None):
+    """CPU only: the per-tile geom masks of the camera-ray bounce (ptx_debug_tile_geoms) for a ctypes Camera, an (n, 6) array of world
+    boxes (lo xyz, hi xyz) and an optional row-tile split (rows, rank, world).  Returns a uint32 array, one word per tile of 256 owned
+    pixels."""
+    L = load_library()
+    b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+    rows, rank, world = tile if tile else (0, 0, 1)
+    cap = (camera.resolution[0] * camera.resolution[1] + 255) // 256 + 1
+    out = np.zeros(cap, np.uint32)
+    n = L.ptx_debug_tile_geoms(C.byref(camera), len(b), _ptr(b), int(bool(depth_of_field)), rows, rank, world, _ptr(out), cap)
+    if n < 0:
+        raise PathTracerError("ptx_debug_tile_geoms: bad argument")
+    return out[:n]
+
+
 def build_library(force=False):
     """Compiles the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH):
@@ -176,6 +191,8 @@ def load_library():
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
     L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
     L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "ptx_debug_tile_geoms"):
+        L.ptx_debug_tile_geoms.restype, L.ptx_debug_tile_geoms.argtypes = i, [vp, i, vp, i, i, i, i, vp, i]
     if hasattr(L, "ptx_kat_fast_exact"):        # (absent from the older builds the A/B scripts load through PTX_AB_LIBRARY)
         L.ptx_kat_fast_exact.restype, L.ptx_kat_fast_exact.argtypes = i, [vp, vp]
     L.ptx_debug_set_capture.restype, L.ptx_debug_set_capture.argtypes = i, [vp, i]

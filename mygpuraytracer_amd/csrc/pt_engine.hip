@@ -860,7 +860,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         Hit hit;
         hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
         if (FIRST && MODE == 0 && tile_subset == 0u) {
-            // Camera rays of a tile into which no geom's box projects (the wide margins of the Cornell frames: over half of C4's tiles):
+            // Camera rays of a tile into which no geom's box projects (the wide margins of the Cornell frames: a third of C4's tiles):
             // every ray misses.  Nothing is generated, tested, ranked or stored -- the paths end black (their slot of the radiance buffer is
             // written), the tile's keys say "no record", and what moves on is the count of survivors in the miss bin (material 0), which
             // the stream indices of the next bounce and the ray statistics are made of.  (The per-tile prefix tables are only ever read
@@ -1848,12 +1848,8 @@ void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6
 // images widened by the LARGEST corner radius; each is then projected to pixels through the pinhole (the relation between a pixel and
 // its focus point) at the four corners of its bounding square.  Anything doubtful -- a corner not in front of the lens plane, a frame
 // whose pixels do not all look towards the same side of it -- keeps the whole frame.
-int update_tile_geoms(ptx_tracer *t) {
-    t->tile_geoms_valid = false;
-    if (!t->cull || t->ngeoms > 32 || t->ngeoms < 1 || getenv("PTX_DEBUG_NO_TILE_GEOMS")) return PTX_OK;
-    const bool dof = t->opt.depth_of_field != 0;
-    if (dof && getenv("PTX_DEBUG_NO_TILE_GEOMS_DOF")) return PTX_OK;
-    const DCamera &c = t->cam;
+// (pure host arithmetic: ptx_debug_tile_geoms hands it to the CPU tests, which check the superset property ray by ray)
+void tile_geom_masks(const DCamera &c, const TileMap &tm, int maxTiles, int ngeoms, const float *aabb8, bool dof, std::vector<uint32_t> &masks) {
     const int W = c.resx, H = c.resy;
     // p - eye = l * (view - R sx - U sy),  R = right * pixelLength.x, U = up * pixelLength.y,  sx = x - W/2, sy = y - H/2  (generateRay)
     const double V[3] = {c.view[0], c.view[1], c.view[2]};
@@ -1884,11 +1880,11 @@ int update_tile_geoms(ptx_tracer *t) {
             zsign = z > 0 ? 1.0 : -1.0;
         }
     }
-    std::vector<int> rect((size_t)t->ngeoms * 4);
-    for (int g = 0; g < t->ngeoms; g++) {
+    std::vector<int> rect((size_t)ngeoms * 4);
+    for (int g = 0; g < ngeoms; g++) {
         int *r = &rect[(size_t)g * 4];
         r[0] = 0; r[1] = W - 1; r[2] = 0; r[3] = H - 1;                  // x0, x1, y0, y1: the whole frame unless proven smaller
-        const float *b = &t->h_aabb[(size_t)g * 8];
+        const float *b = aabb8 + (size_t)g * 8;
         bool ok = std::isfinite(D) && std::fabs(D) > 1e-30 && dof_ok;
         double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
         double cp[8][3], rho = 0.0;
@@ -1926,27 +1922,36 @@ int update_tile_geoms(ptx_tracer *t) {
         r[2] = (int)std::max(0.0, std::min((double)H, std::floor(ylo - m)));
         r[3] = (int)std::max(-1.0, std::min((double)H - 1, std::ceil(yhi + m)));
     }
-    std::vector<uint32_t> masks((size_t)t->maxTiles, 0u);
+    masks.assign((size_t)maxTiles, 0u);
     auto owned_xy = [&](int i, int &x, int &y) {                        // = owned_pixel (device)
         const int r = i / W;
         x = i - r * W;
-        if (t->tm.tile_world <= 1) { y = r; return; }
-        const int k = r / t->tm.tile_rows;
-        y = (k * t->tm.tile_world + t->tm.tile_rank) * t->tm.tile_rows + (r - k * t->tm.tile_rows);
+        if (tm.tile_world <= 1) { y = r; return; }
+        const int k = r / tm.tile_rows;
+        y = (k * tm.tile_world + tm.tile_rank) * tm.tile_rows + (r - k * tm.tile_rows);
     };
-    for (int tile = 0; tile < t->maxTiles; tile++) {
-        const int i0 = tile * TILE, i1 = std::min(i0 + TILE, t->tm.owned) - 1;
+    for (int tile = 0; tile < maxTiles; tile++) {
+        const int i0 = tile * TILE, i1 = std::min(i0 + TILE, tm.owned) - 1;
         if (i1 < i0) { masks[tile] = 0xffffffffu; continue; }
         int x0, y0, x1, y1;
         owned_xy(i0, x0, y0); owned_xy(i1, x1, y1);
         if (y0 != y1) { x0 = 0; x1 = W - 1; }                            // wraps: whole rows y0 .. y1 (rows of other ranks in between included)
         uint32_t m = 0;
-        for (int g = 0; g < t->ngeoms; g++) {
+        for (int g = 0; g < ngeoms; g++) {
             const int *r = &rect[(size_t)g * 4];
             if (!(r[1] < x0 || r[0] > x1 || r[3] < y0 || r[2] > y1)) m |= 1u << g;
         }
         masks[tile] = m;
     }
+}
+
+int update_tile_geoms(ptx_tracer *t) {
+    t->tile_geoms_valid = false;
+    if (!t->cull || t->ngeoms > 32 || t->ngeoms < 1 || getenv("PTX_DEBUG_NO_TILE_GEOMS")) return PTX_OK;
+    const bool dof = t->opt.depth_of_field != 0;
+    if (dof && getenv("PTX_DEBUG_NO_TILE_GEOMS_DOF")) return PTX_OK;
+    std::vector<uint32_t> masks;
+    tile_geom_masks(t->cam, t->tm, t->maxTiles, t->ngeoms, t->h_aabb.data(), dof, masks);
     HIPCHECK(hipMemcpyAsync(t->d_tile_geoms, masks.data(), sizeof(uint32_t) * masks.size(), hipMemcpyHostToDevice, t->stream));
     HIPCHECK(hipStreamSynchronize(t->stream));      // (masks is a local)
     t->tile_geoms_valid = true;
@@ -3188,6 +3193,33 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
 
 // node visits of the last ptx_debug_bvh_check: skip-link walk, front-to-back binary walk, four-wide walk (nodes), wide stack need,
 // sum over groups of 64 consecutive rays of the longest four-wide walk in the group, number of groups, triangles the four-wide walk tested
+// CPU-only: the per-tile geom masks of the camera-ray bounce (update_tile_geoms) for a camera, a tile split and a list of world boxes
+// (6 floats each: lo xyz, hi xyz), without a tracer or a device.  masks_out[tile], tiles of 256 owned pixels; returns the number of tiles
+// (negative: bad argument).
+int ptx_debug_tile_geoms(const ptx_camera *camera, int ngeoms, const float *boxes6, int depth_of_field, int tile_rows, int tile_rank, int tile_world,
+                         uint32_t *masks_out, int max_tiles) {
+    if (!camera || !boxes6 || !masks_out || ngeoms < 1 || ngeoms > 32 || camera->resolution[0] < 1 || camera->resolution[1] < 1)
+    { set_error(PTX_ERR_INVALID, "ptx_debug_tile_geoms: bad argument"); return -1; }
+    DCamera cam;
+    camera_to_device(*camera, cam);
+    TileMap tm{};
+    const int W = cam.resx, H = cam.resy;
+    tm.W = W; tm.H = H; tm.tile_world = tile_world < 1 ? 1 : tile_world; tm.tile_rank = tile_rank; tm.tile_rows = tm.tile_world > 1 ? tile_rows : H;
+    if (tm.tile_world > 1 && (tile_rows < 1 || tile_rank < 0 || tile_rank >= tm.tile_world)) return -1;
+    int owned_rows = 0;
+    for (int y = 0; y < H; y++) if (tm.tile_world <= 1 || (y / tm.tile_rows) % tm.tile_world == tm.tile_rank) owned_rows++;
+    tm.owned = owned_rows * W;
+    const int ntiles = (std::max(tm.owned, 1) + TILE - 1) / TILE;
+    if (ntiles > max_tiles) return -1;
+    std::vector<float> a8((size_t)ngeoms * 8, 0.f);
+    for (int g = 0; g < ngeoms; g++)
+        for (int k = 0; k < 3; k++) { a8[(size_t)g * 8 + k] = boxes6[g * 6 + k]; a8[(size_t)g * 8 + 4 + k] = boxes6[g * 6 + 3 + k]; }
+    std::vector<uint32_t> masks;
+    tile_geom_masks(cam, tm, ntiles, ngeoms, a8.data(), depth_of_field != 0, masks);
+    memcpy(masks_out, masks.data(), sizeof(uint32_t) * (size_t)ntiles);
+    return ntiles;
+}
+
 int ptx_debug_bvh_visits(int64_t out8[8]) {
     if (!out8) return set_error(PTX_ERR_INVALID, "null argument");
     for (int k = 0; k < 8; k++) out8[k] = g_bvh_visits[k];
