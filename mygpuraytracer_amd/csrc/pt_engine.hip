@@ -1226,6 +1226,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
 #ifndef PT_MESH_NMIN
 #define PT_MESH_NMIN 32       // lanes holding an inner node that make the next round a node round
 #endif
+#ifndef PT_MESH_WG_PER_CU
+#define PT_MESH_WG_PER_CU 3    // workgroups per CU of k_mesh's grid (see enqueue_batch)
+#endif
 #ifndef PT_MESH_ONE_TRI
 #define PT_MESH_ONE_TRI 0     // 1: a leaf round tests ONE triangle of the leaf in hand; 0: all of them (measured: 0.54 against 0.61 ms per
                               // iteration at 4K -- the kernel waits for memory more than it issues, and a leaf's triangles share cache lines)
@@ -2163,7 +2166,11 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
             // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy: as many entries as the longest walk needs
             // (k_mesh's waves draw from the segment's queue until it is empty: one round of the kernel's occupancy is all the grid needs)
-            const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WAVES) / K);
+            // Three workgroups per CU, not the five its LDS would admit: a workgroup holds 31 KB (the walks' stacks), five of them nearly all
+            // of a CU's 160 KB -- while k_mesh runs, the OTHER launch sets' kernels then find no LDS to start in and the overlap of the three
+            // sets stops.  With three, k_mesh alone is 4 % slower and C5's wall time 2 % shorter (1.066 -> 1.045 ms per iteration; 4: 1.054,
+            // 2: 1.059; nine runs each on one box); a wave also draws from 460 rays instead of 270.
+            const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WG_PER_CU) / K);
             if (first) KT(2, { hipLaunchKernelGGL(k_mesh<true>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
                                hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
             else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
