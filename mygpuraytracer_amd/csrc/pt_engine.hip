@@ -2067,14 +2067,31 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     // The launch's workgroups: one round of the kernel's occupancy over the whole chip, WHATEVER one segment holds (round 3: until
     // then the total was capped by one segment's tile count, so the K = 10 segments of a 1/8 tile ran as 1010 workgroups of ten
     // tiles -- 4 per CU -- instead of 1790 of six: 20 steps of such a tile 0.636 -> 0.585 ms, tools/gpu_tile_grid_sweep.py)
-    int grid = t->grid_forced ? t->grid : t->cus * (fast_unsplit ? (defer ? PT_FAST_WAVES - 2 : PT_FAST_WAVES) : t->split_mesh ? 16 : 8);
-    if (t->dbg_total_wg_per_cu > 0) grid = t->cus * t->dbg_total_wg_per_cu;      // tuning experiments
-    int gx = grid / K;                               // workgroups per segment
-    if (gx < 64 && t->dbg_total_wg_per_cu <= 0) gx = 64;
-    if (gx > t->maxTiles) gx = t->maxTiles;
-    if (gx > t->grid_seg) gx = t->grid_seg;
-    if (gx > grid) gx = grid;
-    if (gx < 1) gx = 1;
+    // Round 4: MORE workgroups than one round of the occupancy.  A workgroup owns a contiguous chunk of tiles, and chunks are unequal --
+    // the camera-ray bounce's tiles cost anything from nothing (a tile that sees no geom) to a full tile, the later bounces' tiles
+    // differ by material mix -- so with one chunk per resident workgroup a kernel ends when its heaviest chunk does; and the other launch
+    // sets' short kernels (k_finish, the ranking pass) get a slot only when a workgroup of the long one retires.  Measured on one box
+    // each (gpurun_out/r4_c4wg*.log, r4_bouncewg*.log): C4 camera bounce alone 0.0365 (7 per CU) / 0.0338 (14) / 0.0320 (21) / 0.0300 ms
+    // (28), later bounces 0.163 / 0.161 / 0.160 / 0.160 / 0.173 (42), wall of the 20-step run 0.176 / 0.172 / 0.173 / 0.173 / 0.179;
+    // C5 (split bounce) 16 per CU 1.06-1.10, 32 1.03-1.07, 48 1.04-1.07 ms per iteration.
+    // (traced ahead of per-call requests: five per CU, so that two slots stay free for the caller's own short kernels)
+    auto per_cu = [&](bool first_bounce) {
+        if (fast_unsplit) return defer ? PT_FAST_WAVES - 2 : first_bounce ? 28 : 14;
+        return t->split_mesh ? 32 : 8;
+    };
+    auto gx_of = [&](bool first_bounce) {
+        int grid = t->grid_forced ? t->grid : t->cus * per_cu(first_bounce);
+        if (t->dbg_total_wg_per_cu > 0) grid = t->cus * t->dbg_total_wg_per_cu;      // tuning experiments
+        int g = grid / K;                            // workgroups per segment
+        if (g < 64 && t->dbg_total_wg_per_cu <= 0) g = 64;
+        if (g > t->maxTiles) g = t->maxTiles;
+        if (g > t->grid_seg) g = t->grid_seg;
+        if (g > grid) g = grid;
+        return g < 1 ? 1 : g;
+    };
+    const int gx_first = gx_of(true), gx_later = gx_of(false);
+    const int grid = t->cus * (t->dbg_total_wg_per_cu > 0 ? t->dbg_total_wg_per_cu : per_cu(false));      // (k_finish's grid-stride launch)
+    const int gx = gx_later;
     const int nsuper = (gx + 63) / 64;
     const size_t chunk_cap = (size_t)nb * t->grid_seg;                 // runs per table at most
     const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * 3 * chunk_cap, seg_totals = t->seg_totals;
@@ -2136,7 +2153,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.in_totals = first ? nullptr : from_cache ? t->d_cache_totals : totals(b - 1, 0);
         bp.in_super = first ? nullptr : from_cache ? t->d_cache_super : supers(b - 1, 0);
         bp.in_chunk = first ? nullptr : from_cache ? t->d_cache_chunk : chunks(b - 1);
-        bp.in_gx = from_cache ? t->cache_gx : gx;
+        const int gx_b = first ? gx_first : gx_later;                       // this launch's workgroups per segment
+        bp.in_gx = from_cache ? t->cache_gx : (b == 1 ? gx_first : gx_later);      // ... and those of the launch whose run tables it reads
         bp.seg_in_totals = from_cache ? 0 : seg_totals; bp.seg_in_chunk = from_cache ? 0 : seg_chunk;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
@@ -2163,7 +2181,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             bp.item_cursor = bp.item_count + K;
             bp.tile_done = (first && t->d_tile_done) ? t->d_tile_done + seg0 * (size_t)t->maxTiles : nullptr;
             HIPCHECK(hipMemsetAsync(bp.item_count, 0, sizeof(int32_t) * 2 * (size_t)K, stream));
-            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 1, needs_albedo, dim3(gx_b, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
             // the per-lane traversal stack lives in LDS and is what limits k_mesh's occupancy: as many entries as the longest walk needs
             // (k_mesh's waves draw from the segment's queue until it is empty: one round of the kernel's occupancy is all the grid needs)
             // Three workgroups per CU, not the five its LDS would admit: a workgroup holds 31 KB (the walks' stacks), five of them nearly all
@@ -2176,24 +2194,24 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
                          hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
-            KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
+            KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx_b, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.item_cursor = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
-            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
+            KT(first ? 0 : 1, { int rcl = launch_bounce(t, first, 0, needs_albedo, dim3(gx_b, K), lds_bounce, stream, bp); if (rcl != PTX_OK) return rcl; });
         }
 
         if (first && fill_cache) {
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cache_super, supers(0, 0), sizeof(int32_t) * 2 * nb * t->nsuper, hipMemcpyDeviceToDevice, stream));
-            t->cache_gx = gx;
+            t->cache_gx = gx_b;
             t->cache_valid = true;
         }
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
             // (K == 1, lane 0: segment 0 of the buffers)
             int32_t *gs = t->d_cap + 3 * (size_t)t->cap + nb, *ga = gs + chunk_cap + 1;
-            hipLaunchKernelGGL(k_capture_prefix, dim3(1), dim3(64), 0, stream, bp.chunk, (int)chunk_cap, nb * gx, gs, ga);
+            hipLaunchKernelGGL(k_capture_prefix, dim3(1), dim3(64), 0, stream, bp.chunk, (int)chunk_cap, nb * gx_b, gs, ga);
             hipLaunchKernelGGL(k_capture, dim3(std::min(1024, (t->cap + 255) / 256)), dim3(256), 0, stream, bp.stage, bp.chunk, (int)chunk_cap,
-                               nb * gx, gs, ga, t->cap, t->d_cap, t->d_cap_f);
+                               nb * gx_b, gs, ga, t->cap, t->d_cap, t->d_cap_f);
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
             t->cap_filled = true;
         }

@@ -10,6 +10,9 @@ ensure_standin_assets()
 SCENE = sys.argv[1] if len(sys.argv) > 1 else "cornellSpaceship20k.txt"
 ITERS = int(os.environ.get("C5_ITERS", "64"))
 s = pt.Scene(os.path.join(ROOT, "scenes", SCENE), res=(3840, 2160), depth=8); s.apply_runcuda_camera()
-with pt.Tracer(s, depth_of_field=1, lanes=1) as T:
-    T.render(1, ITERS); T.synchronize()
+LANES = int(os.environ.get("C5_LANES", "1"))        # (3: the default plan, for the timeline; 1: kernels alone, for durations and counters)
+with pt.Tracer(s, depth_of_field=1, lanes=LANES) as T:
+    if LANES > 1:
+        T.render(1, 36); T.synchronize()
+    T.render(1000, ITERS); T.synchronize()
     print("loop ms per iteration", T.last_loop_ms() / ITERS)
