@@ -2083,6 +2083,13 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         int grid = t->grid_forced ? t->grid : t->cus * per_cu(first_bounce);
         if (t->dbg_total_wg_per_cu > 0) grid = t->cus * t->dbg_total_wg_per_cu;      // tuning experiments
         int g = grid / K;                            // workgroups per segment
+        if (!t->grid_forced && t->dbg_total_wg_per_cu <= 0) {
+            // ... but only where a workgroup keeps at least ~8 tiles of the camera bounce: a rank's 1/8 tile is a chain of dependent round
+            // trips per workgroup life, and more workgroups are more prologues there -- 20 steps of such a tile 0.54 -> 0.60 ms
+            // with the larger grids.  Below that the grid is one round of the occupancy, as before.
+            const int base = t->cus * (fast_unsplit ? (defer ? PT_FAST_WAVES - 2 : PT_FAST_WAVES) : t->split_mesh ? 16 : 8) / K;
+            g = std::min(g, std::max(base, t->maxTiles / 8));
+        }
         if (g < 64 && t->dbg_total_wg_per_cu <= 0) g = 64;
         if (g > t->maxTiles) g = t->maxTiles;
         if (g > t->grid_seg) g = t->grid_seg;
