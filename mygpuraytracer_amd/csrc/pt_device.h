@@ -95,7 +95,16 @@ PT_HD vec3 multiplyMV(const float *__restrict__ m, vec3 v, float w) {
 }
 
 // ---- portable libm (same operation sequence as the CPU checker's copy; binary64, one rounding to binary32) ----
-// sin and cos of a float argument, |x| <= 1e5: Cody-Waite reduction by pi/2, Taylor polynomials.
+// fma(a, b, c) for a wave-uniform c held in a scalar register pair (the compiler's own choice, v_fmac_f64, needs c in vector registers)
+PT_DEV double fma_sk(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+// sin and cos of a float argument, |x| <= 1e5: Cody-Waite reduction by pi/2, Taylor polynomials in Horner form with FUSED
+// multiply-adds (25 binary64 instructions instead of 40; fused operations are IEEE operations, the checker's copy runs the same ones).
+// On every binary32 with |x| <= 2 pi -- all the path tracer ever passes -- the results equal those of the separate-multiply-add form
+// of rounds 1-3 (tools/sincos_fma_exhaustive.c: 2 173 837 242 arguments, 0 differ), so no fixture moved.
 PT_DEV void sincos_own(float xf, float *s, float *c) {
     const double INVPIO2 = 0x1.45f306dc9c883p-1;
     const double PIO2_1 = 0x1.921fb54400000p+0;
@@ -105,31 +114,33 @@ PT_DEV void sincos_own(float xf, float *s, float *c) {
     double y = x * INVPIO2;
     int k = (int)(y + (y >= 0.0 ? 0.5 : -0.5));
     double kd = (double)k;
-    double r = (x - kd * PIO2_1) - kd * PIO2_1T;
+    double r = __builtin_fma(-kd, PIO2_1T, __builtin_fma(-kd, PIO2_1, x));
     double z = r * r;
+    // (a Horner step as ONE v_fma_f64 whose addend is a scalar register pair -- written out, because the compiler prefers v_fmac_f64, whose
+    // addend is its destination: it moves every coefficient into a vector pair first, two more vector instructions per step.  The
+    // innermost step has two coefficients and a vector instruction reads one scalar pair: it stays a multiplication and an addition.)
     double ps = -0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49;
-    ps = 0x1.6124613a86d09p-33 + z * ps;
-    ps = -0x1.ae64567f544e4p-26 + z * ps;
-    ps = 0x1.71de3a556c734p-19 + z * ps;
-    ps = -0x1.a01a01a01a01ap-13 + z * ps;
-    ps = 0x1.1111111111111p-7 + z * ps;
-    ps = -0x1.5555555555555p-3 + z * ps;
-    double sr = r + r * (z * ps);
+    ps = fma_sk(z, ps, 0x1.6124613a86d09p-33);
+    ps = fma_sk(z, ps, -0x1.ae64567f544e4p-26);
+    ps = fma_sk(z, ps, 0x1.71de3a556c734p-19);
+    ps = fma_sk(z, ps, -0x1.a01a01a01a01ap-13);
+    ps = fma_sk(z, ps, 0x1.1111111111111p-7);
+    ps = fma_sk(z, ps, -0x1.5555555555555p-3);
+    double sr = __builtin_fma(r, z * ps, r);
     double pc = -0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45;
-    pc = 0x1.1eed8eff8d898p-29 + z * pc;
-    pc = -0x1.27e4fb7789f5cp-22 + z * pc;
-    pc = 0x1.a01a01a01a01ap-16 + z * pc;
-    pc = -0x1.6c16c16c16c17p-10 + z * pc;
-    pc = 0x1.5555555555555p-5 + z * pc;
-    pc = -0x1.0000000000000p-1 + z * pc;
-    double cr = 1.0 + z * pc;
-    double sd, cd;
-    switch (k & 3) {
-    case 0: sd = sr; cd = cr; break;
-    case 1: sd = cr; cd = -sr; break;
-    case 2: sd = -sr; cd = -cr; break;
-    default: sd = -cr; cd = sr; break;
-    }
+    pc = fma_sk(z, pc, 0x1.1eed8eff8d898p-29);
+    pc = fma_sk(z, pc, -0x1.27e4fb7789f5cp-22);
+    pc = fma_sk(z, pc, 0x1.a01a01a01a01ap-16);
+    pc = fma_sk(z, pc, -0x1.6c16c16c16c17p-10);
+    pc = fma_sk(z, pc, 0x1.5555555555555p-5);
+    pc = __builtin_fma(z, pc, -0.5);
+    double cr = __builtin_fma(z, pc, 1.0);
+    // quadrant k & 3: (s, c) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr) -- odd k swaps, bit 1 of k negates the sine and bit 1 of
+    // k + 1 the cosine (a negation is the sign bit: selects and two exclusive-ors instead of a four-way branch the wave would diverge on)
+    const bool swap = (k & 1) != 0;
+    const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
+    const double sd = __hiloint2double(__double2hiint(s0) ^ (int)(((uint32_t)k & 2u) << 30), __double2loint(s0));
+    const double cd = __hiloint2double(__double2hiint(c0) ^ (int)(((uint32_t)(k + 1) & 2u) << 30), __double2loint(c0));
     *s = (float)sd;
     *c = (float)cd;
 }
@@ -280,7 +291,7 @@ struct DScene {
     int32_t ntri_lds;                   // triangles staged with them: ntri, or 0 when the mesh tables stay in global memory
     const float *__restrict__ gtab;     // 40 words per geom: inverseTransform rows 0-2 (12), transform rows 0-2 (12),
                                         // invTranspose rows 0-2 (12), type, materialid, faceStart, faceCount
-    const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box (min xyz, pad, max xyz, pad), or NULL
+    const float *__restrict__ aabb;     // 8 floats per geom: conservative world-space box as (centre xyz, pad, half extent xyz, pad), or NULL
     uint32_t cube_bits, sphere_bits, mesh_bits;   // bit i: geom i is a cube / sphere / mesh (unknown types are in none)
     const BvhQuad *__restrict__ bvh_nodes;          // threaded BVH of the larger meshes (pt_bvh.h), or NULL
     const float *__restrict__ bvh_tris;             // BVH_TRI words per leaf triangle
@@ -988,18 +999,22 @@ PT_DEV uint32_t cullMask(const DScene &sc, Ray ray, uint32_t subset = 0xffffffff
     const float ddz = __builtin_fabsf(ray.d.z) < tiny ? __builtin_copysignf(tiny, ray.d.z) : ray.d.z;
     const float ix = __builtin_amdgcn_rcpf(ddx), iy = __builtin_amdgcn_rcpf(ddy), iz = __builtin_amdgcn_rcpf(ddz);
     // This pre-test is not the reference's arithmetic (it only has to be conservative, and the boxes are inflated by 1e-3 +
-    // 1e-4 |coordinate|, four orders of magnitude beyond its rounding), so each plane costs ONE fused multiply-add,
-    // t = plane * (1/d) - o * (1/d), instead of a subtraction and a multiplication: a quarter fewer instructions for the
-    // stage that every ray runs against every geom.
+    // 1e-4 |coordinate|, four orders of magnitude beyond its rounding).  The table holds a box as CENTRE and HALF EXTENT
+    // (world_box_centre_half): with m = (c - o) / d the slab of an axis is [m - h / |d|, m + h / |d|] whatever the sign of d -- three
+    // fused multiply-adds per axis (the centre and the half extent are scalar operands) and no per-axis minimum / maximum, which
+    // issue at 0.64 of a multiply-add's rate on this chip: 13 instead of 16 vector instructions per geom for the stage that every
+    // ray runs against every geom.
     const float ox = -(ray.o.x * ix), oy = -(ray.o.y * iy), oz = -(ray.o.z * iz);
+    const float ax = __builtin_fabsf(ix), ay = __builtin_fabsf(iy), az = __builtin_fabsf(iz);
     uint32_t mask = 0;
     const int n = sc.ngeoms;
     auto slab = [&](const float *bx) {
-        const float x0 = __builtin_fmaf(bx[0], ix, ox), x1 = __builtin_fmaf(bx[4], ix, ox);
-        const float y0 = __builtin_fmaf(bx[1], iy, oy), y1 = __builtin_fmaf(bx[5], iy, oy);
-        const float z0 = __builtin_fmaf(bx[2], iz, oz), z1 = __builtin_fmaf(bx[6], iz, oz);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const float mx = __builtin_fmaf(bx[0], ix, ox), my = __builtin_fmaf(bx[1], iy, oy), mz = __builtin_fmaf(bx[2], iz, oz);
+        const float x0 = __builtin_fmaf(bx[4], -ax, mx), x1 = __builtin_fmaf(bx[4], ax, mx);
+        const float y0 = __builtin_fmaf(bx[5], -ay, my), y1 = __builtin_fmaf(bx[5], ay, my);
+        const float z0 = __builtin_fmaf(bx[6], -az, mz), z1 = __builtin_fmaf(bx[6], az, mz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(x0, y0), z0);
+        const float tf = __builtin_fminf(__builtin_fminf(x1, y1), z1);
         return !((tf < tn) || (tf < 0.0f));      // any NaN => not culled
     };
     if (SUBSET) {
@@ -1018,13 +1033,26 @@ PT_DEV uint32_t cullMask(const DScene &sc, Ray ray, uint32_t subset = 0xffffffff
         }
         return mask;
     }
-    for (int i = 0; i < n; i += 2) {
-        const int j = i + 1 < n ? i + 1 : i;
+    // From the last geom down, two boxes per trip, each verdict shifted in from the right (mask + mask + verdict: ONE add-with-carry
+    // whose carry is the compare's result, instead of a move, a select and an or): geom 0's verdict arrives last and is bit 0.
+    int i = n - 1;
+    if (n & 1) {
+        float bx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) bx[k] = ab[i * 8 + k];
+        mask = slab(bx) ? 1u : 0u;
+        i--;
+    }
+    for (; i > 0; i -= 2) {
         float bx[2][8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[j * 8 + k]; }
+        for (int k = 0; k < 8; k++) { bx[0][k] = ab[i * 8 + k]; bx[1][k] = ab[(i - 1) * 8 + k]; }
 #pragma unroll
-        for (int h = 0; h < 2; h++) mask |= slab(bx[h]) ? (1u << (h ? j : i)) : 0u;
+        for (int h = 0; h < 2; h++) {
+            const unsigned long long verdict = __builtin_amdgcn_ballot_w64(slab(bx[h]));
+            // (written out: the compiler turns `mask + mask + verdict` back into a shift, a select and an or)
+            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mask) : "s"(verdict) : "vcc");
+        }
     }
     return mask;
 }

@@ -1837,6 +1837,20 @@ void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6
     }
 }
 
+// The same box as the device's candidate pre-test reads it (cullMask): centre and half extent.  The half extent grows by what the two
+// roundings can lose (half an ulp of the centre, half an ulp of itself) and then some; an unbounded box is centre 0, half extent inf.
+void world_box_centre_half(const float lohi8[8], float out8[8]) {
+    for (int r = 0; r < 3; r++) {
+        const double lo = lohi8[r], hi = lohi8[4 + r];
+        if (!(lo > -1e30 && hi < 1e30)) { out8[r] = 0.f; out8[4 + r] = INFINITY; continue; }
+        const float c = (float)(0.5 * (lo + hi));
+        const double h = std::max(hi - (double)c, (double)c - lo);
+        out8[r] = c;
+        out8[4 + r] = nextafterf((float)(h + 2e-7 * (std::fabs((double)c) + h)), INFINITY);
+    }
+    out8[3] = out8[7] = 0.f;
+}
+
 // Which geoms can the camera rays of a tile reach at all?  Per geom the pixel rectangle that its conservative world box projects
 // into (double precision, widened by the antialiasing jitter and two more pixels); a corner at or behind the eye plane makes it the
 // whole frame.  A tile is 256 consecutive OWNED pixels: one span of a row, or -- when it wraps -- whole rows.  Bit g of a tile's
@@ -2565,8 +2579,12 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     HC(hipMemcpy(t->d_tri9, htri9.data(), sizeof(float) * htri9.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_gtab, sizeof(float) * hgtab.size()));
     HC(hipMemcpy(t->d_gtab, hgtab.data(), sizeof(float) * hgtab.size(), hipMemcpyHostToDevice));
-    HC(hipMalloc(&t->d_aabb, sizeof(float) * haabb.size()));
-    HC(hipMemcpy(t->d_aabb, haabb.data(), sizeof(float) * haabb.size(), hipMemcpyHostToDevice));
+    {   // (the device reads the boxes as centre + half extent; the host keeps corners for the camera tile masks)
+        std::vector<float> hch(haabb.size(), 0.f);
+        for (int i = 0; i < ngeoms; i++) world_box_centre_half(&haabb[(size_t)i * 8], &hch[(size_t)i * 8]);
+        HC(hipMalloc(&t->d_aabb, sizeof(float) * hch.size()));
+        HC(hipMemcpy(t->d_aabb, hch.data(), sizeof(float) * hch.size(), hipMemcpyHostToDevice));
+    }
     t->h_aabb = haabb;
     HC(hipMalloc(&t->d_texels, htex.size()));
     HC(hipMemcpy(t->d_texels, htex.data(), htex.size(), hipMemcpyHostToDevice));

@@ -62,8 +62,10 @@ void o_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int o_get_libm(void) { return g_libm_mode; }
 
 /* Portable sin/cos for float arguments: Cody-Waite reduction by pi/2 and Taylor polynomials, all in binary64
- * with one final rounding to binary32.  Only +,-,* and int conversion are used, so the HIP kernels can run the
- * same sequence (mygpuraytracer_amd/csrc carries its own copy; the product never includes this file).
+ * with one final rounding to binary32.  Only +, -, *, fused multiply-add (an IEEE operation: fma() here, v_fma_f64 there) and int
+ * conversion are used, so the HIP kernels can run the same sequence (mygpuraytracer_amd/csrc carries its own copy; the product never
+ * includes this file).  Round 4 fused the Horner steps; on every binary32 with |x| <= 2 pi the results equal the unfused form's
+ * (tools/sincos_fma_exhaustive.c), so the fixtures made with the unfused form stand.
  * Domain: |x| <= 1e5 (the path tracer calls it on [0, 2*pi] and [-pi/4, pi]); outside, NaN.               */
 static void own_sincos_d(double x, double *s, double *c) {
     static const double INVPIO2 = 0x1.45f306dc9c883p-1;
@@ -73,24 +75,24 @@ static void own_sincos_d(double x, double *s, double *c) {
     double y = x * INVPIO2;
     int k = (int)(y + (y >= 0.0 ? 0.5 : -0.5));
     double kd = (double)k;
-    double r = (x - kd * PIO2_1) - kd * PIO2_1T;
+    double r = fma(-kd, PIO2_1T, fma(-kd, PIO2_1, x));
     double z = r * r;
-    double ps = -0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49;
-    ps = 0x1.6124613a86d09p-33 + z * ps;
-    ps = -0x1.ae64567f544e4p-26 + z * ps;
-    ps = 0x1.71de3a556c734p-19 + z * ps;
-    ps = -0x1.a01a01a01a01ap-13 + z * ps;
-    ps = 0x1.1111111111111p-7 + z * ps;
-    ps = -0x1.5555555555555p-3 + z * ps;
-    double sr = r + r * (z * ps);
+    double ps = -0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49;      /* (the innermost steps stay unfused: see the device's copy) */
+    ps = fma(z, ps, 0x1.6124613a86d09p-33);
+    ps = fma(z, ps, -0x1.ae64567f544e4p-26);
+    ps = fma(z, ps, 0x1.71de3a556c734p-19);
+    ps = fma(z, ps, -0x1.a01a01a01a01ap-13);
+    ps = fma(z, ps, 0x1.1111111111111p-7);
+    ps = fma(z, ps, -0x1.5555555555555p-3);
+    double sr = fma(r, z * ps, r);
     double pc = -0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45;
-    pc = 0x1.1eed8eff8d898p-29 + z * pc;
-    pc = -0x1.27e4fb7789f5cp-22 + z * pc;
-    pc = 0x1.a01a01a01a01ap-16 + z * pc;
-    pc = -0x1.6c16c16c16c17p-10 + z * pc;
-    pc = 0x1.5555555555555p-5 + z * pc;
-    pc = -0x1.0000000000000p-1 + z * pc;
-    double cr = 1.0 + z * pc;
+    pc = fma(z, pc, 0x1.1eed8eff8d898p-29);
+    pc = fma(z, pc, -0x1.27e4fb7789f5cp-22);
+    pc = fma(z, pc, 0x1.a01a01a01a01ap-16);
+    pc = fma(z, pc, -0x1.6c16c16c16c17p-10);
+    pc = fma(z, pc, 0x1.5555555555555p-5);
+    pc = fma(z, pc, -0x1.0000000000000p-1);
+    double cr = fma(z, pc, 1.0);
     switch (k & 3) {
     case 0: *s = sr; *c = cr; break;
     case 1: *s = cr; *c = -sr; break;
