@@ -256,6 +256,10 @@ int ptx_kat_fast_exact(ptx_tracer *t, int64_t mismatches[3]);
  * row-tile split.  Returns the number of tiles, -1 on a bad argument.  The CPU tests check the superset property ray by ray. */
 int ptx_debug_tile_geoms(const ptx_camera *camera, int ngeoms, const float *boxes6, int depth_of_field, int tile_rows, int tile_rank,
                          int tile_world, uint32_t *masks_out, int max_tiles);
+/* CPU-only: the table the candidate pre-test (the conservative world boxes every ray is tested against before the exact tests) reads on
+ * the device, for n corner boxes (lo xyz, hi xyz): 8 floats per box = centre xyz, 0, half extent xyz, 0.  The CPU tests check that it
+ * contains the corner box and that the device's slab arithmetic on it never rejects a ray that reaches the corner box. */
+int ptx_debug_cull_boxes(int n, const float *boxes6, float *centre_half8);
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */

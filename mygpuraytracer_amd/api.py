@@ -88,6 +88,17 @@ def debug_tile_geoms(camera, boxes6, depth_of_field=False, tile=None):
     return out[:n]
 
 
+def debug_cull_boxes(boxes6):
+    """CPU only: the device's table of the candidate pre-test (ptx_debug_cull_boxes) for an (n, 6) array of corner boxes: (n, 8) float32,
+    centre xyz, 0, half extent xyz, 0."""
+    L = load_library()
+    b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+    out = np.zeros((len(b), 8), np.float32)
+    if L.ptx_debug_cull_boxes(len(b), _ptr(b), _ptr(out)) < 0:
+        raise PathTracerError("ptx_debug_cull_boxes: bad argument")
+    return out
+
+
 def build_library(force=False):
     """Compiles the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH):
@@ -193,6 +204,8 @@ def load_library():
     L.ptx_kat_libm.restype, L.ptx_kat_libm.argtypes = i, [vp, i, vp, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "ptx_debug_tile_geoms"):
         L.ptx_debug_tile_geoms.restype, L.ptx_debug_tile_geoms.argtypes = i, [vp, i, vp, i, i, i, i, vp, i]
+    if hasattr(L, "ptx_debug_cull_boxes"):
+        L.ptx_debug_cull_boxes.restype, L.ptx_debug_cull_boxes.argtypes = i, [i, vp, vp]
     if hasattr(L, "ptx_kat_fast_exact"):        # (absent from the older builds the A/B scripts load through PTX_AB_LIBRARY)
         L.ptx_kat_fast_exact.restype, L.ptx_kat_fast_exact.argtypes = i, [vp, vp]
     L.ptx_debug_set_capture.restype, L.ptx_debug_set_capture.argtypes = i, [vp, i]

@@ -2779,6 +2779,10 @@ int ptx_reset_image(ptx_tracer *t) {
     return PTX_OK;
 }
 
+// Experiment hook (PTX_DEBUG_PREQUEUE_US): one lane that holds the main stream for that long, so that the host has queued the whole run
+// before its first kernel starts -- what a replayed launch graph would look like from the device's side.  The loop timer starts behind it.
+namespace { __global__ void k_hold(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32); } }
+
 int ptx_render(ptx_tracer *t, int iter_first, int count) { return ptx_render_strided(t, iter_first, count, 1); }
 
 int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
@@ -2794,6 +2798,7 @@ int ptx_render_strided(ptx_tracer *t, int iter_first, int count, int stride) {
         t->loop_ms_total += ms;
         t->timing_valid = false;
     }
+    if (const char *e = getenv("PTX_DEBUG_PREQUEUE_US")) hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, t->stream, (long long)atoi(e) * 100);      // (100 MHz)
     HIPCHECK(hipEventRecord(t->ev_start, t->stream));
     // per-kernel timing and the debug capture look at one launch set at a time
     // A run shorter than lanes x kmax iterations is cut into equal launch sets, one per lane, as long as each keeps at
@@ -3242,6 +3247,17 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
 }
 
 // node visits of the last ptx_debug_bvh_check: skip-link walk, front-to-back binary walk, four-wide walk (nodes), wide stack need,
+// CPU-only: the candidate pre-test's table (world_box_centre_half) for n corner boxes (lo xyz, hi xyz): 8 floats each = centre xyz, 0,
+// half extent xyz, 0 -- what cullMask reads on the device.
+int ptx_debug_cull_boxes(int n, const float *boxes6, float *centre_half8) {
+    if (n < 0 || (n && (!boxes6 || !centre_half8))) { set_error(PTX_ERR_INVALID, "ptx_debug_cull_boxes: bad argument"); return -1; }
+    for (int g = 0; g < n; g++) {
+        const float lohi[8] = {boxes6[g * 6], boxes6[g * 6 + 1], boxes6[g * 6 + 2], 0.f, boxes6[g * 6 + 3], boxes6[g * 6 + 4], boxes6[g * 6 + 5], 0.f};
+        world_box_centre_half(lohi, centre_half8 + (size_t)g * 8);
+    }
+    return n;
+}
+
 // sum over groups of 64 consecutive rays of the longest four-wide walk in the group, number of groups, triangles the four-wide walk tested
 // CPU-only: the per-tile geom masks of the camera-ray bounce (update_tile_geoms) for a camera, a tile split and a list of world boxes
 // (6 floats each: lo xyz, hi xyz), without a tracer or a device.  masks_out[tile], tiles of 256 owned pixels; returns the number of tiles
