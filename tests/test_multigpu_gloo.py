@@ -197,7 +197,7 @@ def _worker_gather(rank, world, port, q, W, H, rows):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,rows", [(3, 16, 41, 4), (2, 8, 7, 8)])
+@pytest.mark.parametrize("world,W,H,rows", [(3, 16, 41, 4), (2, 8, 7, 8), (8, 16, 1080, 8), (4, 12, 2160, 8)])      # (the last two: the row layout of the 8- and 4-GPU runs of C4 and C5)
 def test_gather_of_owned_rows_equals_the_reduce(world, W, H, rows):
     """multigpu.assemble_tiles: ranks own different numbers of rows (41 rows in blocks of 4 over 3 ranks; a rank that owns
     nothing: 7 rows in one block of 8 over 2 ranks) -- the packs are padded, the frame assembled on rank 0 equals what
