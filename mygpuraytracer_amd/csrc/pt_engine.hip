@@ -85,6 +85,9 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #endif
 constexpr int TILE = PT_TILE;      // paths per tile = threads per workgroup (PT_TILE / 64 waves)
 constexpr int WAVES = TILE / 64;
+// a path's rank inside its tile takes RANK_BITS; the stage key packs bin | rank among all << BIN_BITS | rank among the stored << (BIN_BITS + RANK_BITS)
+constexpr int RANK_BITS = TILE <= 256 ? 8 : 9, BIN_BITS = 32 - 2 * RANK_BITS;
+static_assert(TILE <= 512 && (TILE & (TILE - 1)) == 0, "tile size: a power of two up to 512 (9-bit ranks)");
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
 // tileIntersect's 2 x 4 list counters
 // + the window over the input's run tables (locate): 65 start positions, 65 stream-index bases, 64 local-index bases, next run
@@ -138,7 +141,7 @@ struct PathSoA {
 constexpr int SOA_FLOATS = 14, SOA_INTS = 5;
 
 // stage key: bin | rank among all survivors of the tile << 16 | rank among the stored ones << 24 (ranks < 256)
-__device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << 16) | ((uint32_t)r_scat << 24)); }
+__device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << BIN_BITS) | ((uint32_t)r_scat << (BIN_BITS + RANK_BITS))); }
 
 __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
     s.f += off; s.i += off;
@@ -347,7 +350,7 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
     const float *gtab = reinterpret_cast<const float *>(pt_lds) + sc.ntri_lds * 24 + sc.nmats * 11;
     float *rayb = reinterpret_cast<float *>(scratch);                              // [6][TILE]
     unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 6 * TILE);   // [TILE]
-    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [CAP] ray | geom << 8: cubes from the front,
+    uint16_t *list = reinterpret_cast<uint16_t *>(scratch + 8 * TILE);             // [CAP] ray | geom << RANK_BITS: cubes from the front,
     uint16_t *listM = list + ITEMS_PER_PASS * TILE;                                // spheres from the back; [CAP] meshes
     constexpr int CAP = ITEMS_PER_PASS * TILE;
     uint32_t cube_mask = 0, sph_mask = 0, mesh_mask = 0;
@@ -391,17 +394,17 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
         for (int j = 0; j < nc; j++) {
             const int g = __ffs((int)cube_mask) - 1;
             cube_mask &= cube_mask - 1;
-            list[base[0] + j] = (uint16_t)(tid | (g << 8));
+            list[base[0] + j] = (uint16_t)(tid | (g << RANK_BITS));
         }
         for (int j = 0; j < ns; j++) {
             const int g = __ffs((int)sph_mask) - 1;
             sph_mask &= sph_mask - 1;
-            list[CAP - 1 - (base[1] + j)] = (uint16_t)(tid | (g << 8));
+            list[CAP - 1 - (base[1] + j)] = (uint16_t)(tid | (g << RANK_BITS));
         }
         for (int j = 0; j < nm; j++) {
             const int g = __ffs((int)mesh_mask) - 1;
             mesh_mask &= mesh_mask - 1;
-            listM[base[2] + j] = (uint16_t)(tid | (g << 8));
+            listM[base[2] + j] = (uint16_t)(tid | (g << RANK_BITS));
         }
         __syncthreads();
         const int totC = tcnt[4 * q + 0], totS = tcnt[4 * q + 1], totM = tcnt[4 * q + 2], more = tcnt[4 * q + 3];
@@ -425,7 +428,7 @@ __device__ __forceinline__ void tileIntersect(const DScene &sc, bool alive, Ray 
                 item = listM[kk];
             }
             if (item >= 0) {
-                const int src = item & 0xff, g = item >> 8;
+                const int src = item & (TILE - 1), g = item >> RANK_BITS;
                 Ray r;
                 r.o = V3(rayb[0 * TILE + src], rayb[1 * TILE + src], rayb[2 * TILE + src]);
                 r.d = V3(rayb[3 * TILE + src], rayb[4 * TILE + src], rayb[5 * TILE + src]);
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             // (every ray is finished by now: by pass 1, or -- the ones with mesh candidates -- by k_finish)
             if (i < n_in) {
                 if (FIRST) k1 = ld_u(stage.lsrc(), (uint32_t)i << 2);
-                myslot = (k1 >> 16) & 0xff;
+                myslot = (k1 >> 16) & (TILE - 1);
                 alive = (k1 & K1_ALIVE) != 0; pending = (k1 & K1_PEND) != 0; bin = k1 & 0xffff;
             }
         } else if (alive) {
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             for (int u = 0; u < MOVE_U; u++) {
                 if (key[u] == -1) continue;
                 const int tile = tbase + u;
-                const int bin = key[u] & 0xffff, r_all = (key[u] >> 16) & 0xff, r_scat = (key[u] >> 24) & 0xff;
+                const int bin = key[u] & ((1 << BIN_BITS) - 1), r_all = (key[u] >> BIN_BITS) & (TILE - 1), r_scat = (int)((uint32_t)key[u] >> (BIN_BITS + RANK_BITS));
                 const uint32_t c4 = (uint32_t)(bin * p.maxTiles + tile) << 2;      // (a segment's table is below 4 GiB: ptx_create)
                 const int pos = tile0 * TILE + cbb[bin] + ld_u(counts_scat, c4) + r_scat;
                 st_u(stage.lsrc(), (uint32_t)pos << 2, (int32_t)(tile * TILE + tid));
@@ -2349,7 +2352,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         return set_error(PTX_ERR_INVALID, "missing scene arrays");
     if (camera->resolution[0] <= 0 || camera->resolution[1] <= 0) return set_error(PTX_ERR_INVALID, "resolution must be positive");
     if (trace_depth < 1) return set_error(PTX_ERR_UNSUPPORTED, "trace depth must be >= 1");
-    if (nmaterials > 65535 || ngeoms > 32767) return set_error(PTX_ERR_UNSUPPORTED, "more than 65535 materials or 32767 geoms");
+    if (nmaterials >= (1 << BIN_BITS) || ngeoms > 32767) return set_error(PTX_ERR_UNSUPPORTED, "more than 65535 materials or 32767 geoms");
     ptx_options opt;
     if (options) opt = *options; else ptx_default_options(&opt);
     if (opt.bounding_box) return set_error(PTX_ERR_UNSUPPORTED, "BOUNDING_BOX culling is off in the reference and not implemented");
