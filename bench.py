@@ -532,6 +532,14 @@ def main():
                 lane_slots = insts * 64 / avg_s
                 valu_issue = dict(achieved=lane_slots / 1e12, peak=VALU_PEAK / 1e12, unit="T lane-slots/s", frac=lane_slots / VALU_PEAK,
                                   wave_instructions_per_launch=insts, lanes_active=(k.get("_derived") or {}).get("valu_lane_utilisation"),
+                                  # `peak` is the textbook one instruction per 4 cycles and SIMD.  Measured on this chip (tools/micro/valu_rates.hip,
+                                  # wall clock, 8 waves per SIMD; profiles/round4_valu_rates.txt): plain fp32 / integer-add / logic instructions
+                                  # retire one per 2.5 cycles, min / max / select / compare / shift / binary64 / packed ones one per 4.1, a stream
+                                  # mixed like k_bounce's one per 3.06 -- the capacity the second fraction is taken of
+                                  cycles_per_instruction_per_simd=avg_s * 2.4e9 * 1024 / insts,
+                                  measured_capacity_cycles_per_instruction=dict(plain=2.54, second_class=4.09, k_bounce_like_mix=3.06,
+                                                                                source="profiles/round4_valu_rates.txt"),
+                                  frac_of_measured_mix_capacity=3.06 / (avg_s * 2.4e9 * 1024 / insts),
                                   source="profiles/sq_latest.json (SQ_INSTS_VALU per launch from %s, not this run%s) x 64 lanes / this run's "
                                          "launch time / (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)" % (
                                              sq.get("_how", "tools/pmc_sq.sh"), "; scaled by rays per launch" if ref_units else ""))
