@@ -67,6 +67,10 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #ifndef PT_MESH_WAVES
 #define PT_MESH_WAVES 5       // waves per SIMD k_mesh is compiled for
 #endif
+#ifndef PT_EXP_CARRY_UV
+#define PT_EXP_CARRY_UV 0     // experiment only (1: the specialised kernel carries the two texcoord fields it has no use for: +8 B read per ray, +8 B written per
+                              // stored path, same results -- what the wall time makes of 8 % more HBM traffic, profiles/experiments/README.md)
+#endif
 #ifndef PT_PARK_STATE
 #define PT_PARK_STATE 1       // specialised unsplit k_bounce: state that is idle during the pair tests waits in LDS, not in registers
 #endif
@@ -235,6 +239,8 @@ struct BounceParams {
     int32_t *tile_done;                    // split first bounce: [segment][tile] 1 = pass 1 finished the tile (no ray of it reaches a mesh's box)
     int32_t aa, dof, sort;
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
+    unsigned long long dir_bins;           // bit b: the records of material bin b carry the incoming direction (reflective, refractive, or a
+                                           // material of an OBJ geom: what scatterRay reads it for); the other bins' records do not
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
     float *albedo;
     int32_t nbins, maxTiles;
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.sc.cull = 1; p.sc.tri_lds = 1;
     }
     if (FAST && MODE == 0) {
-        p.uses_uv = 0; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
+        p.uses_uv = PT_EXP_CARRY_UV; p.sort = 1; p.albedo = nullptr; p.emit_count = nullptr; p.dof = 0;
         p.sc.cull = 1; p.sc.tri_lds = 2; p.sc.bump_bits = 0; p.sc.ntri_lds = p.sc.ntri; p.sc.bvh_root = nullptr;
     }
     // dynamic LDS (pt_lds): [scene tables when staged: triangles, materials][2][WAVES][nbins] ranking histogram [2][nbins] running prefix
@@ -665,6 +671,28 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     // (running sum inside the chunk) and no separate scan pass over the tiles is needed
     const int chunk = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tile0 = min((int)blockIdx.x * chunk, ntiles), tile1 = min(tile0 + chunk, ntiles);
+    // Which sorted positions hold records WITH an incoming direction (dir_bins: scatterRay reads it for reflective and refractive materials
+    // and on OBJ geoms; a diffuse hit on a cube or sphere -- most of a Cornell scene -- never does, and its record's three direction
+    // words are neither stored nor loaded: 24 B of the 120 a stored path moves).  The stream is sorted by bin: up to two ranges of
+    // positions, from the input's per-bin totals; anything more complicated keeps every direction.
+    int dir_lo0 = 0, dir_len0 = 0x7fffffff, dir_lo1 = 0, dir_len1 = 0;
+    if (MODE != 2 && !FIRST && nb <= 64 && p.dir_bins != ~0ull) {
+        int lo[2] = {0, 0}, hi[2] = {0, 0}, nr = 0, pos = 0;
+        bool open = false, all = false;
+        for (int b = 0; b < nb; b++) {
+            const int tot = in_totals[nb + b];
+            if (tot > 0) {
+                const bool need = (p.dir_bins >> b) & 1ull;
+                if (need && !open) { if (nr == 2) all = true; else lo[nr] = pos; open = true; }
+                else if (!need && open) { if (nr < 2) hi[nr] = pos; nr++; open = false; }
+            }
+            pos += tot;
+        }
+        if (open) { if (nr < 2) hi[nr] = pos; nr++; }
+        if (!all && nr <= 2) { dir_lo0 = lo[0]; dir_len0 = hi[0] - lo[0]; dir_lo1 = lo[1]; dir_len1 = hi[1] - lo[1]; }
+    }
+    const bool dir_some = MODE != 2 && nb <= 64 && p.dir_bins != ~0ull;      // (uniform: the writer's side of the same rule.  Split bounce: the rays pass 1
+                                                                            // parks keep theirs -- k_mesh walks with it -- whatever their bin turns out to be)
 #ifdef PT_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
 #define STAMP(k) do { st_t1 = __builtin_amdgcn_s_memtime(); st_acc[k] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
@@ -745,7 +773,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
         }
     };
-    auto fetch = [&](uint32_t li4, int idx_base, InRec &r) {
+    auto fetch = [&](uint32_t li4, int idx_base, InRec &r, int jp) {
         const PathSoA in = soa_fresh(in_k);
         // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
         // slot of that bounce's stage and the path's rank inside its run
@@ -753,8 +781,12 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (__builtin_expect(j >= p.fence_slots, 0)) fence_report(p);
         const uint32_t j4 = min(j, p.fence_slots - 1u) << 2;
         r.idx = idx_base + ld_u(in.lidx(), li4);
+        const bool with_dir = (uint32_t)(jp - dir_lo0) < (uint32_t)dir_len0 || (uint32_t)(jp - dir_lo1) < (uint32_t)dir_len1;
 #pragma unroll
-        for (int k = 0; k < 12; k++) r.f[k] = ld_u(in.field(k), j4);
+        for (int k = 0; k < 12; k++) {
+            if (k >= 3 && k < 6) { r.f[k] = 0.f; if (with_dir) r.f[k] = ld_u(in.field(k), j4); }
+            else r.f[k] = ld_u(in.field(k), j4);
+        }
         r.f[12] = r.f[13] = 0.f;
         if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
         r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
@@ -833,7 +865,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 if (tile_subset != 0u) generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                fetch(li4, idx_base, cur);
+                fetch(li4, idx_base, cur, min(i, n_in - 1));
                 const vec3 intersect = V3(cur.f[0], cur.f[1], cur.f[2]);           // stored as origin + t * direction
                 ps.d = V3(cur.f[3], cur.f[4], cur.f[5]);
                 ps.color = V3(cur.f[6], cur.f[7], cur.f[8]);
@@ -1101,10 +1133,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             const vec3 sp = add(ps.o, scale(ps.d, hit.t));      // the point shadeFakeMaterial will shade (:392)
             float *rf = reinterpret_cast<float *>(rec);
             rf[0 * TILE + slot] = sp.x; rf[1 * TILE + slot] = sp.y; rf[2 * TILE + slot] = sp.z;
-            rf[3 * TILE + slot] = ps.d.x; rf[4 * TILE + slot] = ps.d.y; rf[5 * TILE + slot] = ps.d.z;
+            if (!dir_some || ((p.dir_bins >> bin) & 1ull)) { rf[3 * TILE + slot] = ps.d.x; rf[4 * TILE + slot] = ps.d.y; rf[5 * TILE + slot] = ps.d.z; }
             rf[6 * TILE + slot] = ps.color.x; rf[7 * TILE + slot] = ps.color.y; rf[8 * TILE + slot] = ps.color.z;
             rf[9 * TILE + slot] = hit.n.x; rf[10 * TILE + slot] = hit.n.y; rf[11 * TILE + slot] = hit.n.z;
-            rf[12 * TILE + slot] = hit.u; rf[13 * TILE + slot] = hit.v;
+            if (p.uses_uv) { rf[12 * TILE + slot] = hit.u; rf[13 * TILE + slot] = hit.v; }
             rec[14 * TILE + slot] = pix;
             rec[15 * TILE + slot] = hit.mat | (hit.geom << 16);
             rec[16 * TILE + slot] = stage_key(bin, r_all, r_scat);
@@ -1116,12 +1148,18 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             const uint32_t gi4 = (uint32_t)(tile * TILE + tid) << 2;
             if (tid < npend) {
                 const float *rf = reinterpret_cast<const float *>(rec);
+                const int32_t skey = rec[16 * TILE + tid];
+                // (this slot's record carries a direction iff its bin says so: the reader decides by the same bins, from the sorted position)
+                const bool with_dir = !dir_some || ((p.dir_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
 #pragma unroll
-                for (int k = 0; k < 12; k++) st_u(stage.field(k), gi4, rf[k * TILE + tid]);
+                for (int k = 0; k < 12; k++) {
+                    if (k >= 3 && k < 6) { if (with_dir) st_u(stage.field(k), gi4, rf[k * TILE + tid]); }
+                    else st_u(stage.field(k), gi4, rf[k * TILE + tid]);
+                }
                 if (p.uses_uv) { st_u(stage.u(), gi4, rf[12 * TILE + tid]); st_u(stage.v(), gi4, rf[13 * TILE + tid]); }
                 st_u(stage.pix(), gi4, rec[14 * TILE + tid]);
                 st_u(stage.mg(), gi4, rec[15 * TILE + tid]);
-                st_u(stage.idx(), gi4, rec[16 * TILE + tid]);
+                st_u(stage.idx(), gi4, skey);
             } else {
                 st_u(stage.idx(), gi4, (int32_t)-1);
             }
@@ -1745,6 +1783,7 @@ struct ptx_tracer {
     int last_ahead_lane = -1;                            // != -1: the previous operation was a call served from that lane's batch
     hipEvent_t ev_ahead0[MAX_LANES] = {}, ev_ahead1[MAX_LANES] = {};
     int uses_uv = 0;
+    unsigned long long dir_bins = ~0ull;                 // BounceParams::dir_bins (all ones: every record carries its direction)
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
@@ -2182,7 +2221,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.seg_in_totals = from_cache ? 0 : seg_totals; bp.seg_in_chunk = from_cache ? 0 : seg_chunk;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
-        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? ~0ull : t->dir_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
         bp.chunk = to_cache ? t->d_cache_chunk : chunks(b); bp.chunk_cap = (int32_t)chunk_cap;
@@ -2572,6 +2611,17 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
     static_assert(sizeof(DMaterial) == sizeof(ptx_material), "material layout");
     if (nmaterials) memcpy(hm.data(), materials, sizeof(DMaterial) * (size_t)nmaterials);
+    {   // which material bins' records must carry the incoming direction to the next bounce: scatterRay (pt_device.h) reads it in its
+        // reflective and refractive branches and for every hit on an OBJ geom (Schlick's cosine), never for a diffuse cube or sphere hit
+        unsigned long long need = 0;
+        bool all = t->nbins > 64 || nmaterials < 1 || getenv("PTX_DEBUG_NO_DIR_SKIP") != nullptr;
+        for (int m = 0; m < nmaterials && !all; m++) {
+            bool nd = hm[m].hasReflective > 0 || hm[m].hasRefractive > 0;
+            for (int i = 0; i < ngeoms && !nd; i++) nd = hg[i].type == G_OBJ && hg[i].materialid == m;
+            if (nd) need |= 1ull << (opt.sort_by_material ? nmaterials - 1 - m : 0);
+        }
+        t->dir_bins = all ? ~0ull : need;
+    }
     HC(hipMalloc(&t->d_geoms, sizeof(DGeom) * hg.size()));
     HC(hipMemcpy(t->d_geoms, hg.data(), sizeof(DGeom) * hg.size(), hipMemcpyHostToDevice));
     HC(hipMalloc(&t->d_mats, sizeof(DMaterial) * hm.size()));

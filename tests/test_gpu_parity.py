@@ -224,7 +224,16 @@ def test_sorted_stream_parity(gpu_product, O, scene, res, depth, opt):
     T.close()
 
 
-def check_sorted_streams(T, O, d, depth):
+def records_with_direction(d, material_ids):
+    """the rule of ptx_create's dir_bins: a stored path carries its incoming direction iff scatterRay can read it for the material hit --
+    reflective, refractive, or the material of an OBJ geom"""
+    mats, gi = d["materials"], d["geom_ints"]
+    need = (mats[:, 7] > 0) | (mats[:, 8] > 0)
+    need[gi[gi[:, 0] == 3, 1]] = True
+    return need[material_ids]
+
+
+def check_sorted_streams(T, O, d, depth, directions_where_needed_only=False):
     """d = the scene's POD dict (Scene.dump() layout)"""
     mats = d["materials"]
     it = 1
@@ -245,8 +254,14 @@ def check_sorted_streams(T, O, d, depth):
         sp = paths["origin"][pend] + isects["t"][pend][:, None] * paths["direction"][pend]
         for k, nm in enumerate(("px", "py", "pz")):
             assert beq(g[nm], sp[:, k])
+        # (a capture makes every record carry its direction; with PTX_DEBUG_KEEP_DIR_SKIP the kernels run as they do otherwise, and the
+        # words of the records that travel without one are whatever the slot held)
+        with_dir = records_with_direction(d, isects["materialId"][pend]) if directions_where_needed_only else np.ones(int(pend.sum()), bool)
         for k, nm in enumerate(("dx", "dy", "dz")):
-            assert beq(g[nm], paths["direction"][pend][:, k])
+            assert beq(g[nm][with_dir], paths["direction"][pend][with_dir, k])
+        if directions_where_needed_only and bounce == 0 and (~with_dir).any():
+            # ... and the skip is live: what a fresh stage holds in those words is not the paths' directions
+            assert not all(beq(g[nm][~with_dir], paths["direction"][pend][~with_dir, k]) for k, nm in enumerate(("dx", "dy", "dz")))
         for k, nm in enumerate(("cr", "cg", "cb")):
             assert beq(g[nm], paths["color"][pend][:, k])
         for k, nm in enumerate(("nx", "ny", "nz")):
@@ -254,6 +269,31 @@ def check_sorted_streams(T, O, d, depth):
         if d.get("textures"):                                      # texcoords travel only when some texture exists
             obj = d["geom_ints"][isects["geomId"][pend], 0] == 3
             assert beq(g["u"][obj], isects["texcoord"][pend][obj, 0]) and beq(g["v"][obj], isects["texcoord"][pend][obj, 1])
+
+
+@pytest.mark.parametrize("scene,res,depth,opt", [("cornellObj.txt", (192, 108), 8, {}), ("cornellSpaceship.txt", (160, 120), 6, {}),
+                                                  ("cornellSpaceship.txt", (96, 54), 6, dict(no_mesh_split=1)), ("cornellGlass.txt", (96, 96), 8, {})])
+def test_records_without_their_direction_lose_nothing_else(gpu_product, O, monkeypatch, scene, res, depth, opt):
+    """A stored path whose material scatterRay never asks for the incoming direction (a diffuse hit on a cube or sphere) travels without
+    those three words.  With the kernels running exactly as they do outside a capture (PTX_DEBUG_KEEP_DIR_SKIP): every other field of
+    every record, and the direction of every record that needs one, equal the oracle's after every bounce -- in the fused bounce, the
+    split bounce (parked rays keep theirs), the textured mesh inside the bounce kernel and a scene of mostly reflective / refractive
+    hits; both kinds of record occur; and the frame equals the one of a tracer that carries every direction (PTX_DEBUG_NO_DIR_SKIP)."""
+    monkeypatch.setenv("PTX_DEBUG_KEEP_DIR_SKIP", "1")
+    s, T = make_pair(gpu_product, O, scene, res, depth, **opt)
+    d = s.dump()
+    check_sorted_streams(T, O, d, depth, directions_where_needed_only=True)
+    T.debug_capture(-1); T.reset_image()
+    T.render(1, 6)
+    img = T.read_image()
+    T.close()
+    n, paths, isects = oracle_pending_stream(O, 1, 0)
+    need = records_with_direction(d, isects["materialId"][isects["t"] > 0])
+    assert need.any() and (~need).any()
+    monkeypatch.setenv("PTX_DEBUG_NO_DIR_SKIP", "1")
+    with gpu_product.Tracer(s, **opt) as T2:
+        T2.render(1, 6)
+        assert beq(T2.read_image(), img)
 
 
 def test_cottage_mesh_from_vectors_on_device(gpu_product, O):
