@@ -910,6 +910,8 @@ struct Hit {
     vec3 n;
     float u, v;
     int32_t geom, mat;
+    int32_t ncode;    // cube hits: which of the cube's six tabulated normals n is (key aux & 7: axis + 1 | side << 2; 0: none recorded) -- what
+                      // a stored path of a cubes-only material carries instead of the normal itself (cubeNormalByCode); 0 for every other hit
 };
 
 // Header of geom i (transform, inverseTransform, type, material, face range) through the SCALAR memory path: the
@@ -1217,12 +1219,25 @@ PT_DEV unsigned long long meshKey(const DScene &sc, const float *gtab, int g, Ra
     return packKey(t, g, (uint32_t)c.face);
 }
 
+// A cube hit's normal from its 3-bit code (the low bits of its key: axis + 1 | side << 2): the tabulated one, or -- no axis recorded,
+// NaN inputs -- the reference's zero vector through the same arithmetic.  decodeKey's and, for a stored path that carries the code instead
+// of the normal, the next bounce's (same table, same words).
+PT_DEV vec3 cubeNormalByCode(const DScene &sc, const float *gtab, int g, int code) {
+    const int axis = (code & 3) - 1;
+    if (axis >= 0) return cubeNormalTab(sc, g, axis * 2 + ((code & 4) ? 1 : 0));
+    const float *G = gtab + g * 40;
+    float invT[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
+    return normalize(mulRows(invT, V3(0.f, 0.f, 0.f), 0.0f));
+}
+
 // What the winning key stands for: t, geom, material, normal (and texcoords when the scene uses them).
 // NO_MESH: the caller knows the winner is a cube or a sphere (pass 1 of the split bounce finishing a ray that reached no mesh box):
 // the mesh branch -- barycentrics redone, bump map -- is not compiled into that call site.
 template <bool NO_MESH = false>
 PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long key, Ray ray, bool need_uv, Hit &h) {
-    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0;
+    h.t = -1.f; h.n = V3(0.f, 0.f, 0.f); h.u = 0.f; h.v = 0.f; h.geom = 0; h.mat = 0; h.ncode = 0;
     if (key == KEY_NONE) return;
     const int g = (int)((key >> 24) & 0xff);
     const uint32_t aux = (uint32_t)(key & 0xffffffu);
@@ -1257,14 +1272,8 @@ PT_DEV void decodeKey(const DScene &sc, const float *gtab, unsigned long long ke
         }
     } else {
         if (type == G_CUBE) {   // one of six normals per cube, computed at upload (normalize(invTranspose * +-e_axis))
-            const int axis = (int)(aux & 3u) - 1;
-            if (axis >= 0) h.n = cubeNormalTab(sc, g, axis * 2 + ((aux & 4u) ? 1 : 0));
-            else {              // no axis recorded (NaN inputs): the reference's zero vector through the same arithmetic
-                float invT[12];
-#pragma unroll
-                for (int k = 0; k < 12; k++) invT[k] = G[24 + k];
-                h.n = normalize(mulRows(invT, V3(0.f, 0.f, 0.f), 0.0f));
-            }
+            h.ncode = (int32_t)(aux & 7u);
+            h.n = cubeNormalByCode(sc, gtab, g, h.ncode);
         } else {            // sphere: the object-space hit point is recomputed (same arithmetic as in primKey)
             float invT[12];
 #pragma unroll

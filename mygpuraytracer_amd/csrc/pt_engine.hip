@@ -241,6 +241,8 @@ struct BounceParams {
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     unsigned long long dir_bins;           // bit b: the records of material bin b carry the incoming direction (reflective, refractive, or a
                                            // material of an OBJ geom: what scatterRay reads it for); the other bins' records do not
+    unsigned long long ntab_bins;          // bit b: every hit of material bin b is a cube hit (no sphere or OBJ geom has the material): its records
+                                           // carry the 3-bit code of the cube's tabulated normal in pix's bits 28-30 instead of the normal
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
     float *albedo;
     int32_t nbins, maxTiles;
@@ -674,25 +676,31 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     // Which sorted positions hold records WITH an incoming direction (dir_bins: scatterRay reads it for reflective and refractive materials
     // and on OBJ geoms; a diffuse hit on a cube or sphere -- most of a Cornell scene -- never does, and its record's three direction
     // words are neither stored nor loaded: 24 B of the 120 a stored path moves).  The stream is sorted by bin: up to two ranges of
-    // positions, from the input's per-bin totals; anything more complicated keeps every direction.
-    int dir_lo0 = 0, dir_len0 = 0x7fffffff, dir_lo1 = 0, dir_len1 = 0;
-    if (MODE != 2 && !FIRST && nb <= 64 && p.dir_bins != ~0ull) {
+    // positions, from the input's per-bin totals.  In the same way the records of a material that only cubes have carry a 3-bit code of the
+    // cube's tabulated normal (in pix's bits 28-30) instead of the normal: another 24 B; a diffuse wall's record is 32 B instead of 56.
+    // (ptx_create leaves at most two runs of set bits in either mask, so two ranges always do: empty bins only merge them)
+    auto binRanges = [&](unsigned long long mask, int &lo0, int &len0, int &lo1, int &len1) {
         int lo[2] = {0, 0}, hi[2] = {0, 0}, nr = 0, pos = 0;
-        bool open = false, all = false;
+        bool open = false;
         for (int b = 0; b < nb; b++) {
             const int tot = in_totals[nb + b];
             if (tot > 0) {
-                const bool need = (p.dir_bins >> b) & 1ull;
-                if (need && !open) { if (nr == 2) all = true; else lo[nr] = pos; open = true; }
-                else if (!need && open) { if (nr < 2) hi[nr] = pos; nr++; open = false; }
+                const bool set = (mask >> b) & 1ull;
+                if (set && !open) { if (nr < 2) lo[nr] = pos; open = true; }
+                else if (!set && open) { if (nr < 2) hi[nr] = pos; nr++; open = false; }
             }
             pos += tot;
         }
         if (open) { if (nr < 2) hi[nr] = pos; nr++; }
-        if (!all && nr <= 2) { dir_lo0 = lo[0]; dir_len0 = hi[0] - lo[0]; dir_lo1 = lo[1]; dir_len1 = hi[1] - lo[1]; }
-    }
-    const bool dir_some = MODE != 2 && nb <= 64 && p.dir_bins != ~0ull;      // (uniform: the writer's side of the same rule.  Split bounce: the rays pass 1
-                                                                            // parks keep theirs -- k_mesh walks with it -- whatever their bin turns out to be)
+        lo0 = lo[0]; len0 = hi[0] - lo[0]; lo1 = lo[1]; len1 = hi[1] - lo[1];
+    };
+    const bool masks_on = MODE != 2 && nb <= 64;
+    const bool dir_some = masks_on && p.dir_bins != ~0ull;        // (uniform: the writer's side of the same rules.  Split bounce: the rays pass 1
+    const bool ntab_some = masks_on && p.ntab_bins != 0ull;       // parks keep their direction -- k_mesh walks with it -- whatever their bin turns out to be)
+    int dir_lo0 = 0, dir_len0 = 0x7fffffff, dir_lo1 = 0, dir_len1 = 0;      // sorted positions whose records carry a direction: all, unless ...
+    int ntab_lo0 = 0, ntab_len0 = 0, ntab_lo1 = 0, ntab_len1 = 0;           // ... whose records carry a normal code instead of a normal: none, unless ...
+    if (!FIRST && dir_some) binRanges(p.dir_bins, dir_lo0, dir_len0, dir_lo1, dir_len1);
+    if (!FIRST && ntab_some) binRanges(p.ntab_bins, ntab_lo0, ntab_len0, ntab_lo1, ntab_len1);
 #ifdef PT_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
 #define STAMP(k) do { st_t1 = __builtin_amdgcn_s_memtime(); st_acc[k] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
@@ -782,14 +790,21 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const uint32_t j4 = min(j, p.fence_slots - 1u) << 2;
         r.idx = idx_base + ld_u(in.lidx(), li4);
         const bool with_dir = (uint32_t)(jp - dir_lo0) < (uint32_t)dir_len0 || (uint32_t)(jp - dir_lo1) < (uint32_t)dir_len1;
+        const bool coded_n = (uint32_t)(jp - ntab_lo0) < (uint32_t)ntab_len0 || (uint32_t)(jp - ntab_lo1) < (uint32_t)ntab_len1;
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             if (k >= 3 && k < 6) { r.f[k] = 0.f; if (with_dir) r.f[k] = ld_u(in.field(k), j4); }
+            else if (k >= 9) { r.f[k] = 0.f; if (!coded_n) r.f[k] = ld_u(in.field(k), j4); }
             else r.f[k] = ld_u(in.field(k), j4);
         }
         r.f[12] = r.f[13] = 0.f;
         if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
         r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
+        if (coded_n) {      // the cube's tabulated normal, the words decodeKey took it from (the tile path: the tables are staged)
+            const vec3 n = cubeNormalByCode(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, r.mg >> 16, (r.pix >> 28) & 7);
+            r.f[9] = n.x; r.f[10] = n.y; r.f[11] = n.z;
+            r.pix &= 0x0fffffff;
+        }
     };
     auto classifyRay = [&](const Hit &hit, const PathState &ps, int pix, int &bin, bool &pending) {
         classifyPath<FIRST>(p, iter, part, batched, hit, ps.color, pix, bin, pending);
@@ -893,7 +908,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         STAMP(0);        // load + shade (or ray generation)
         // computeIntersections(b) + the terminal cases of shadeFakeMaterial(b)
         Hit hit;
-        hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0;
+        hit.t = -1.f; hit.n = V3(0.f, 0.f, 0.f); hit.u = hit.v = 0.f; hit.geom = 0; hit.mat = 0; hit.ncode = 0;
         if (FIRST && MODE == 0 && tile_subset == 0u) {
             // Camera rays of a tile into which no geom's box projects (the wide margins of the Cornell frames: a third of C4's tiles):
             // every ray misses.  Nothing is generated, tested, ranked or stored -- the paths end black (their slot of the radiance buffer is
@@ -1135,9 +1150,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             rf[0 * TILE + slot] = sp.x; rf[1 * TILE + slot] = sp.y; rf[2 * TILE + slot] = sp.z;
             if (!dir_some || ((p.dir_bins >> bin) & 1ull)) { rf[3 * TILE + slot] = ps.d.x; rf[4 * TILE + slot] = ps.d.y; rf[5 * TILE + slot] = ps.d.z; }
             rf[6 * TILE + slot] = ps.color.x; rf[7 * TILE + slot] = ps.color.y; rf[8 * TILE + slot] = ps.color.z;
-            rf[9 * TILE + slot] = hit.n.x; rf[10 * TILE + slot] = hit.n.y; rf[11 * TILE + slot] = hit.n.z;
+            const bool coded_n = ntab_some && ((p.ntab_bins >> bin) & 1ull);
+            if (!coded_n) { rf[9 * TILE + slot] = hit.n.x; rf[10 * TILE + slot] = hit.n.y; rf[11 * TILE + slot] = hit.n.z; }
             if (p.uses_uv) { rf[12 * TILE + slot] = hit.u; rf[13 * TILE + slot] = hit.v; }
-            rec[14 * TILE + slot] = pix;
+            rec[14 * TILE + slot] = coded_n ? (pix | (hit.ncode << 28)) : pix;
             rec[15 * TILE + slot] = hit.mat | (hit.geom << 16);
             rec[16 * TILE + slot] = stage_key(bin, r_all, r_scat);
         }
@@ -1151,9 +1167,11 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 const int32_t skey = rec[16 * TILE + tid];
                 // (this slot's record carries a direction iff its bin says so: the reader decides by the same bins, from the sorted position)
                 const bool with_dir = !dir_some || ((p.dir_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
+                const bool coded_n = ntab_some && ((p.ntab_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
 #pragma unroll
                 for (int k = 0; k < 12; k++) {
                     if (k >= 3 && k < 6) { if (with_dir) st_u(stage.field(k), gi4, rf[k * TILE + tid]); }
+                    else if (k >= 9) { if (!coded_n) st_u(stage.field(k), gi4, rf[k * TILE + tid]); }
                     else st_u(stage.field(k), gi4, rf[k * TILE + tid]);
                 }
                 if (p.uses_uv) { st_u(stage.u(), gi4, rf[12 * TILE + tid]); st_u(stage.v(), gi4, rf[13 * TILE + tid]); }
@@ -1435,7 +1453,9 @@ __global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
         if (pending) {
             const vec3 sp = add(ray.o, scale(ray.d, hit.t));          // the point shadeFakeMaterial will shade (:392)
             st.px()[sa] = sp.x; st.py()[sa] = sp.y; st.pz()[sa] = sp.z;
-            st.nx()[sa] = hit.n.x; st.ny()[sa] = hit.n.y; st.nz()[sa] = hit.n.z;      // (direction, colour and pixel are in place)
+            // (direction, colour and pixel are in place; a record of a cubes-only material carries its normal as a code in the pixel word)
+            if (p.nbins <= 64 && ((p.ntab_bins >> bin) & 1ull)) st.pix()[sa] = pix | (hit.ncode << 28);
+            else { st.nx()[sa] = hit.n.x; st.ny()[sa] = hit.n.y; st.nz()[sa] = hit.n.z; }
             if (p.uses_uv) { st.u()[sa] = hit.u; st.v()[sa] = hit.v; }
             st.mg()[sa] = hit.mat | (hit.geom << 16);
         }
@@ -1784,6 +1804,7 @@ struct ptx_tracer {
     hipEvent_t ev_ahead0[MAX_LANES] = {}, ev_ahead1[MAX_LANES] = {};
     int uses_uv = 0;
     unsigned long long dir_bins = ~0ull;                 // BounceParams::dir_bins (all ones: every record carries its direction)
+    unsigned long long ntab_bins = 0ull;                 // BounceParams::ntab_bins (none: every record carries its normal)
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
@@ -2221,7 +2242,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.seg_in_totals = from_cache ? 0 : seg_totals; bp.seg_in_chunk = from_cache ? 0 : seg_chunk;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
-        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? ~0ull : t->dir_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? ~0ull : t->dir_bins;
+        bp.ntab_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? 0ull : t->ntab_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
         bp.chunk = to_cache ? t->d_cache_chunk : chunks(b); bp.chunk_cap = (int32_t)chunk_cap;
@@ -2612,15 +2634,32 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     static_assert(sizeof(DMaterial) == sizeof(ptx_material), "material layout");
     if (nmaterials) memcpy(hm.data(), materials, sizeof(DMaterial) * (size_t)nmaterials);
     {   // which material bins' records must carry the incoming direction to the next bounce: scatterRay (pt_device.h) reads it in its
-        // reflective and refractive branches and for every hit on an OBJ geom (Schlick's cosine), never for a diffuse cube or sphere hit
-        unsigned long long need = 0;
-        bool all = t->nbins > 64 || nmaterials < 1 || getenv("PTX_DEBUG_NO_DIR_SKIP") != nullptr;
-        for (int m = 0; m < nmaterials && !all; m++) {
-            bool nd = hm[m].hasReflective > 0 || hm[m].hasRefractive > 0;
-            for (int i = 0; i < ngeoms && !nd; i++) nd = hg[i].type == G_OBJ && hg[i].materialid == m;
-            if (nd) need |= 1ull << (opt.sort_by_material ? nmaterials - 1 - m : 0);
+        // reflective and refractive branches and for every hit on an OBJ geom (Schlick's cosine), never for a diffuse cube or sphere hit;
+        // and which bins' hits are all cube hits (the material is on cubes only): their records carry a code for the cube's tabulated
+        // normal instead of the normal.  The next bounce tells the two kinds of record apart by sorted position -- at most two ranges
+        // each -- so a mask keeps at most two runs of set bits: gaps between the runs of the first are FILLED (a direction more is
+        // harmless), runs beyond the second of the other are CLEARED.
+        unsigned long long need = 0, cubes = 0;
+        const bool off = t->nbins > 64 || nmaterials < 1 || getenv("PTX_DEBUG_NO_DIR_SKIP") != nullptr;
+        for (int m = 0; m < nmaterials && !off; m++) {
+            bool nd = hm[m].hasReflective > 0 || hm[m].hasRefractive > 0, on_cube = false, on_other = false;
+            for (int i = 0; i < ngeoms; i++)
+                if (hg[i].materialid == m) { nd = nd || hg[i].type == G_OBJ; (hg[i].type == G_CUBE ? on_cube : on_other) = true; }
+            const int b = opt.sort_by_material ? nmaterials - 1 - m : 0;
+            if (nd) need |= 1ull << b;
+            if (on_cube && !on_other && opt.sort_by_material) cubes |= 1ull << b;
         }
-        t->dir_bins = all ? ~0ull : need;
+        auto runs = [&](unsigned long long mask) { int n = 0; for (int b = 0; b < t->nbins; b++) n += ((mask >> b) & 1) && !(b && ((mask >> (b - 1)) & 1)); return n; };
+        while (runs(need) > 2) {                          // fill the gap behind the first run
+            int b = 0;
+            while (!((need >> b) & 1)) b++;
+            while ((need >> b) & 1) b++;
+            need |= 1ull << b;
+        }
+        while (runs(cubes) > 2) cubes &= ~(1ull << (63 - __builtin_clzll(cubes)));      // drop the highest set bin
+        t->dir_bins = off ? ~0ull : need;
+        // (the code rides in bits 28-30 of the pixel slot; the tabulated normals are what the tile path's decodeKey reads)
+        t->ntab_bins = (off || !t->cull || t->tm.owned >= (1 << 28) || getenv("PTX_DEBUG_NO_NORMAL_CODES")) ? 0ull : cubes;
     }
     HC(hipMalloc(&t->d_geoms, sizeof(DGeom) * hg.size()));
     HC(hipMemcpy(t->d_geoms, hg.data(), sizeof(DGeom) * hg.size(), hipMemcpyHostToDevice));
