@@ -112,43 +112,58 @@ static_assert((6 * TILE) % 2 == 0 && (8 * TILE) % 2 == 0, "tileIntersect's 64-bi
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order; the sort exists only as the chunk-local index in their lsrc / lidx arrays plus the run tables.
 struct PathSoA {
-    // field k of the floats starts at f + k * stride, of the ints at i + k * stride (stride = segments x capacity; a
-    // segment's part of a field starts seg * capacity further).  Kept as base + stride rather than 17 pointers: a kernel
+    // What every stored path carries lies in TWO arrays of 16-byte quads per slot -- (shading point xyz, pixel slot) and (throughput colour
+    // rgb, materialId | geomId << 16): one 16-byte load or store each, and a run of a tile's records of one bin is 16 B per record and
+    // array, not 4: a run's first and last cache lines, which the neighbouring bins' readers fetch as well, are a fifth of what it
+    // reads instead of half (round 4: the wall time follows the HBM bytes).  What only some records carry -- incoming direction, normal,
+    // texcoords -- stays in plain arrays of their own, field k at f + k * stride; the ints at i + k * stride (stride = segments x capacity;
+    // a segment's part of an array starts seg * capacity slots further).  Kept as bases + stride rather than a pointer per field: a kernel
     // that holds two of these in scalar registers for its whole tile loop has none left for anything else.
-    float *f;
-    int32_t *i;
+    float *q;          // [2][stride] quads
+    float *f;          // [8][stride]: dx dy dz, nx ny nz, u, v
+    int32_t *i;        // [3][stride]: idx, lsrc, lidx
     uint32_t stride;
-    __host__ __device__ float *field(int k) const { return f + (size_t)k * stride; }
-    __host__ __device__ float *px() const { return field(0); }      // shading point = origin + t * direction (src/pathtrace.cu:392)
-    __host__ __device__ float *py() const { return field(1); }
-    __host__ __device__ float *pz() const { return field(2); }
-    __host__ __device__ float *dx() const { return field(3); }      // incoming direction
-    __host__ __device__ float *dy() const { return field(4); }
-    __host__ __device__ float *dz() const { return field(5); }
-    __host__ __device__ float *cr() const { return field(6); }      // throughput colour
-    __host__ __device__ float *cg() const { return field(7); }
-    __host__ __device__ float *cb() const { return field(8); }
-    __host__ __device__ float *nx() const { return field(9); }      // pending intersection: normal, texcoord (u, v only if textured)
-    __host__ __device__ float *ny() const { return field(10); }
-    __host__ __device__ float *nz() const { return field(11); }
-    __host__ __device__ float *u() const { return field(12); }
-    __host__ __device__ float *v() const { return field(13); }
-    __host__ __device__ int32_t *pix() const { return i; }                          // pixelIndex (global, x + y*W)
-    __host__ __device__ int32_t *mg() const { return i + (size_t)stride; }          // materialId | geomId << 16
-    __host__ __device__ int32_t *idx() const { return i + 2 * (size_t)stride; }     // stage key (see stage_key) or -1
+    struct F4 { float *b; __host__ __device__ float &operator[](size_t s) const { return b[s * 4]; } };      // one component of a quad array
+    struct I4 { int32_t *b; __host__ __device__ int32_t &operator[](size_t s) const { return b[s * 4]; } };
+    __host__ __device__ float *quadA() const { return q; }                              // px py pz pix
+    __host__ __device__ float *quadB() const { return q + 4 * (size_t)stride; }         // cr cg cb mg
+    __host__ __device__ F4 px() const { return {q}; }              // shading point = origin + t * direction (src/pathtrace.cu:392)
+    __host__ __device__ F4 py() const { return {q + 1}; }
+    __host__ __device__ F4 pz() const { return {q + 2}; }
+    __host__ __device__ I4 pix() const { return {reinterpret_cast<int32_t *>(q) + 3}; }                          // slot among the owned pixels
+    __host__ __device__ F4 cr() const { return {quadB()}; }        // throughput colour
+    __host__ __device__ F4 cg() const { return {quadB() + 1}; }
+    __host__ __device__ F4 cb() const { return {quadB() + 2}; }
+    __host__ __device__ I4 mg() const { return {reinterpret_cast<int32_t *>(quadB()) + 3}; }                     // materialId | geomId << 16
+    __host__ __device__ float *dx() const { return f; }             // incoming direction (records of the bins in dir_bins only)
+    __host__ __device__ float *dy() const { return f + (size_t)stride; }
+    __host__ __device__ float *dz() const { return f + 2 * (size_t)stride; }
+    __host__ __device__ float *nx() const { return f + 3 * (size_t)stride; }      // pending intersection: normal (not the records of ntab_bins), texcoord (u, v only if textured)
+    __host__ __device__ float *ny() const { return f + 4 * (size_t)stride; }
+    __host__ __device__ float *nz() const { return f + 5 * (size_t)stride; }
+    __host__ __device__ float *u() const { return f + 6 * (size_t)stride; }
+    __host__ __device__ float *v() const { return f + 7 * (size_t)stride; }
+    // logical field k of slot j, in the order the debug capture hands them out: point, direction, colour, normal, u, v
+    __host__ __device__ float fieldAt(int k, size_t j) const {
+        if (k < 3) return q[j * 4 + k];
+        if (k < 6) return f[(size_t)(k - 3) * stride + j];
+        if (k < 9) return quadB()[j * 4 + (k - 6)];
+        return f[(size_t)(k - 6) * stride + j];
+    }
+    __host__ __device__ int32_t *idx() const { return i; }     // stage key (see stage_key) or -1
     // the chunk-local sorted index a workgroup leaves in its tail (see "local move" in k_bounce): entry e of the chunk's region is
     // the stage slot of the path that comes e-th in (bin, tile, rank) order inside the chunk, and its rank among ALL survivors of
     // its bin inside the chunk (the part of the RNG stream index the workgroup can know by itself)
-    __host__ __device__ int32_t *lsrc() const { return i + 3 * (size_t)stride; }
-    __host__ __device__ int32_t *lidx() const { return i + 4 * (size_t)stride; }
+    __host__ __device__ int32_t *lsrc() const { return i + (size_t)stride; }
+    __host__ __device__ int32_t *lidx() const { return i + 2 * (size_t)stride; }
 };
-constexpr int SOA_FLOATS = 14, SOA_INTS = 5;
+constexpr int SOA_FLOATS = 16, SOA_INTS = 3, SOA_LOGICAL_FLOATS = 14;      // words per slot in the float / int buffers; fields the capture hands out
 
 // stage key: bin | rank among all survivors of the tile << 16 | rank among the stored ones << 24 (ranks < 256)
 __device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << BIN_BITS) | ((uint32_t)r_scat << (BIN_BITS + RANK_BITS))); }
 
 __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
-    s.f += off; s.i += off;
+    s.q += 4 * off; s.f += off; s.i += off;
     return s;
 }
 // The same stream, but with a stride the optimiser cannot see through: field addresses derived from the result are
@@ -791,15 +806,17 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         r.idx = idx_base + ld_u(in.lidx(), li4);
         const bool with_dir = (uint32_t)(jp - dir_lo0) < (uint32_t)dir_len0 || (uint32_t)(jp - dir_lo1) < (uint32_t)dir_len1;
         const bool coded_n = (uint32_t)(jp - ntab_lo0) < (uint32_t)ntab_len0 || (uint32_t)(jp - ntab_lo1) < (uint32_t)ntab_len1;
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            if (k >= 3 && k < 6) { r.f[k] = 0.f; if (with_dir) r.f[k] = ld_u(in.field(k), j4); }
-            else if (k >= 9) { r.f[k] = 0.f; if (!coded_n) r.f[k] = ld_u(in.field(k), j4); }
-            else r.f[k] = ld_u(in.field(k), j4);
-        }
+        typedef float quad __attribute__((ext_vector_type(4)));
+        const uint32_t j16 = j4 << 2;
+        const quad A = ld_u(reinterpret_cast<const quad *>(in.quadA()), j16), B = ld_u(reinterpret_cast<const quad *>(in.quadB()), j16);
+        r.f[0] = A.x; r.f[1] = A.y; r.f[2] = A.z; r.pix = __float_as_int(A.w);
+        r.f[6] = B.x; r.f[7] = B.y; r.f[8] = B.z; r.mg = __float_as_int(B.w);
+        r.f[3] = r.f[4] = r.f[5] = 0.f;
+        if (with_dir) { r.f[3] = ld_u(in.dx(), j4); r.f[4] = ld_u(in.dy(), j4); r.f[5] = ld_u(in.dz(), j4); }
+        r.f[9] = r.f[10] = r.f[11] = 0.f;
+        if (!coded_n) { r.f[9] = ld_u(in.nx(), j4); r.f[10] = ld_u(in.ny(), j4); r.f[11] = ld_u(in.nz(), j4); }
         r.f[12] = r.f[13] = 0.f;
         if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
-        r.pix = ld_u(in.pix(), j4); r.mg = ld_u(in.mg(), j4);
         if (coded_n) {      // the cube's tabulated normal, the words decodeKey took it from (the tile path: the tables are staged)
             const vec3 n = cubeNormalByCode(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, r.mg >> 16, (r.pix >> 28) & 7);
             r.f[9] = n.x; r.f[10] = n.y; r.f[11] = n.z;
@@ -1168,15 +1185,16 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 // (this slot's record carries a direction iff its bin says so: the reader decides by the same bins, from the sorted position)
                 const bool with_dir = !dir_some || ((p.dir_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
                 const bool coded_n = ntab_some && ((p.ntab_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
-#pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    if (k >= 3 && k < 6) { if (with_dir) st_u(stage.field(k), gi4, rf[k * TILE + tid]); }
-                    else if (k >= 9) { if (!coded_n) st_u(stage.field(k), gi4, rf[k * TILE + tid]); }
-                    else st_u(stage.field(k), gi4, rf[k * TILE + tid]);
-                }
+                typedef float quad __attribute__((ext_vector_type(4)));
+                const uint32_t gi16 = gi4 << 2;
+                quad A, B;
+                A.x = rf[0 * TILE + tid]; A.y = rf[1 * TILE + tid]; A.z = rf[2 * TILE + tid]; A.w = rf[14 * TILE + tid];
+                B.x = rf[6 * TILE + tid]; B.y = rf[7 * TILE + tid]; B.z = rf[8 * TILE + tid]; B.w = rf[15 * TILE + tid];
+                st_u(reinterpret_cast<quad *>(stage.quadA()), gi16, A);
+                st_u(reinterpret_cast<quad *>(stage.quadB()), gi16, B);
+                if (with_dir) { st_u(stage.dx(), gi4, rf[3 * TILE + tid]); st_u(stage.dy(), gi4, rf[4 * TILE + tid]); st_u(stage.dz(), gi4, rf[5 * TILE + tid]); }
+                if (!coded_n) { st_u(stage.nx(), gi4, rf[9 * TILE + tid]); st_u(stage.ny(), gi4, rf[10 * TILE + tid]); st_u(stage.nz(), gi4, rf[11 * TILE + tid]); }
                 if (p.uses_uv) { st_u(stage.u(), gi4, rf[12 * TILE + tid]); st_u(stage.v(), gi4, rf[13 * TILE + tid]); }
-                st_u(stage.pix(), gi4, rec[14 * TILE + tid]);
-                st_u(stage.mg(), gi4, rec[15 * TILE + tid]);
                 st_u(stage.idx(), gi4, skey);
             } else {
                 st_u(stage.idx(), gi4, (int32_t)-1);
@@ -1485,7 +1503,7 @@ __global__ void k_capture(PathSoA stage, const int32_t *chunk, int chunk_cap, in
         int j = stage.lsrc()[li];
         j = j < 0 ? 0 : (j >= cap ? cap - 1 : j);
         out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = ga[lo] + stage.lidx()[li]; out_i[2 * (size_t)cap + k] = stage.mg()[j];
-        for (int f = 0; f < SOA_FLOATS; f++) out_f[(size_t)f * cap + k] = stage.field(f)[j];
+        for (int f = 0; f < SOA_LOGICAL_FLOATS; f++) out_f[(size_t)f * cap + k] = stage.fieldAt(f, (size_t)j);
     }
 }
 
@@ -1844,11 +1862,11 @@ namespace {
 
 // field arrays of `stride` elements each (stride = segments x cap: segment s of a field starts at s*cap)
 void carve(PathSoA &s, float *f, int32_t *i, size_t stride) {
-    s.f = f; s.i = i; s.stride = (uint32_t)stride;
+    s.q = f; s.f = f + 8 * stride; s.i = i; s.stride = (uint32_t)stride;
 }
 
 PathSoA soa_shift(PathSoA s, size_t off) {       // host side of soa_offset: the same fields `off` elements further
-    s.f += off; s.i += off;
+    s.q += 4 * off; s.f += off; s.i += off;
     return s;
 }
 
@@ -3410,7 +3428,7 @@ int ptx_debug_set_capture(ptx_tracer *t, int bounce) {
     if (bounce >= 0 && !t->d_cap) {
         // pix, stream index, material|geom [cap each], the bounce's totals [nbins], run prefixes of the capture [2][nbins x grid_seg + 1]
         HIPCHECK(hipMalloc(&t->d_cap, sizeof(int32_t) * (3 * (size_t)t->cap + (size_t)t->nbins + 2 * ((size_t)t->nbins * t->grid_seg + 1))));
-        HIPCHECK(hipMalloc(&t->d_cap_f, sizeof(float) * SOA_FLOATS * (size_t)t->cap));
+        HIPCHECK(hipMalloc(&t->d_cap_f, sizeof(float) * SOA_LOGICAL_FLOATS * (size_t)t->cap));
     }
     return PTX_OK;
 }
@@ -3432,7 +3450,7 @@ int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32
         HIPCHECK(hipMemcpy(pixel_index, t->d_cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
         if (t->tm.tile_world > 1)             // paths carry their slot among the owned pixels: report the pixel (x + y*W)
             for (int k = 0; k < m; k++) {
-                const int slot = pixel_index[k], r = slot / t->tm.W, x = slot - r * t->tm.W, blk = r / t->tm.tile_rows;
+                const int slot = pixel_index[k] & 0x0fffffff, r = slot / t->tm.W, x = slot - r * t->tm.W, blk = r / t->tm.tile_rows;
                 pixel_index[k] = x + ((blk * t->tm.tile_world + t->tm.tile_rank) * t->tm.tile_rows + (r - blk * t->tm.tile_rows)) * t->tm.W;
             }
         HIPCHECK(hipMemcpy(stream_idx, t->d_cap + t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
@@ -3440,7 +3458,7 @@ int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32
         HIPCHECK(hipMemcpy(mg.data(), t->d_cap + 2 * (size_t)t->cap, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost));
         for (int k = 0; k < m; k++) material[k] = mg[k] & 0xffff;
         if (fields14)       // 14 rows of m floats: px py pz dx dy dz cr cg cb nx ny nz u v
-            for (int f = 0; f < SOA_FLOATS; f++)
+            for (int f = 0; f < SOA_LOGICAL_FLOATS; f++)
                 HIPCHECK(hipMemcpy(fields14 + (size_t)f * m, t->d_cap_f + (size_t)f * t->cap, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
     }
     return PTX_OK;
