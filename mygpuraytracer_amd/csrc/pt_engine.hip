@@ -112,21 +112,22 @@ static_assert((6 * TILE) % 2 == 0 && (8 * TILE) % 2 == 0, "tileIntersect's 64-bi
 // SoA stream.  "stream" buffers hold paths waiting to be shaded (sorted); "stage" buffers hold the output of
 // k_bounce in tile order; the sort exists only as the chunk-local index in their lsrc / lidx arrays plus the run tables.
 struct PathSoA {
-    // What every stored path carries lies in TWO arrays of 16-byte quads per slot -- (shading point xyz, pixel slot) and (throughput colour
-    // rgb, materialId | geomId << 16): one 16-byte load or store each, and a run of a tile's records of one bin is 16 B per record and
-    // array, not 4: a run's first and last cache lines, which the neighbouring bins' readers fetch as well, are a fifth of what it
-    // reads instead of half (round 4: the wall time follows the HBM bytes).  What only some records carry -- incoming direction, normal,
-    // texcoords -- stays in plain arrays of their own, field k at f + k * stride; the ints at i + k * stride (stride = segments x capacity;
-    // a segment's part of an array starts seg * capacity slots further).  Kept as bases + stride rather than a pointer per field: a kernel
-    // that holds two of these in scalar registers for its whole tile loop has none left for anything else.
-    float *q;          // [2][stride] quads
-    float *f;          // [8][stride]: dx dy dz, nx ny nz, u, v
+    // A stored path lies in up to FOUR arrays of 16-byte quads per slot: A = (shading point xyz, pixel slot) and B = (throughput colour rgb,
+    // materialId | geomId << 16), which every record has; C = (normal xyz, texcoord u) unless the record's bin is in ntab_bins; D = (incoming
+    // direction xyz, texcoord v) if its bin is in dir_bins.  One 16-byte load or store per part, and a run of a tile's records of one bin
+    // is 16 B per record and array, not 4: the run's first and last cache lines, which the neighbouring bins' readers fetch as well, are
+    // a fifth of what it reads instead of half (round 4: the wall time follows the HBM bytes).  The ints lie at i + k * stride (stride =
+    // segments x capacity; a segment's part of an array starts seg * capacity slots further).  Kept as bases + stride rather than a pointer
+    // per field: a kernel that holds two of these in scalar registers for its whole tile loop has none left for anything else.
+    float *q;          // [4][stride] quads
     int32_t *i;        // [3][stride]: idx, lsrc, lidx
     uint32_t stride;
     struct F4 { float *b; __host__ __device__ float &operator[](size_t s) const { return b[s * 4]; } };      // one component of a quad array
     struct I4 { int32_t *b; __host__ __device__ int32_t &operator[](size_t s) const { return b[s * 4]; } };
     __host__ __device__ float *quadA() const { return q; }                              // px py pz pix
     __host__ __device__ float *quadB() const { return q + 4 * (size_t)stride; }         // cr cg cb mg
+    __host__ __device__ float *quadC() const { return q + 8 * (size_t)stride; }         // nx ny nz u
+    __host__ __device__ float *quadD() const { return q + 12 * (size_t)stride; }        // dx dy dz v
     __host__ __device__ F4 px() const { return {q}; }              // shading point = origin + t * direction (src/pathtrace.cu:392)
     __host__ __device__ F4 py() const { return {q + 1}; }
     __host__ __device__ F4 pz() const { return {q + 2}; }
@@ -135,20 +136,21 @@ struct PathSoA {
     __host__ __device__ F4 cg() const { return {quadB() + 1}; }
     __host__ __device__ F4 cb() const { return {quadB() + 2}; }
     __host__ __device__ I4 mg() const { return {reinterpret_cast<int32_t *>(quadB()) + 3}; }                     // materialId | geomId << 16
-    __host__ __device__ float *dx() const { return f; }             // incoming direction (records of the bins in dir_bins only)
-    __host__ __device__ float *dy() const { return f + (size_t)stride; }
-    __host__ __device__ float *dz() const { return f + 2 * (size_t)stride; }
-    __host__ __device__ float *nx() const { return f + 3 * (size_t)stride; }      // pending intersection: normal (not the records of ntab_bins), texcoord (u, v only if textured)
-    __host__ __device__ float *ny() const { return f + 4 * (size_t)stride; }
-    __host__ __device__ float *nz() const { return f + 5 * (size_t)stride; }
-    __host__ __device__ float *u() const { return f + 6 * (size_t)stride; }
-    __host__ __device__ float *v() const { return f + 7 * (size_t)stride; }
+    __host__ __device__ F4 nx() const { return {quadC()}; }        // pending intersection: normal, texcoords (u, v only if textured)
+    __host__ __device__ F4 ny() const { return {quadC() + 1}; }
+    __host__ __device__ F4 nz() const { return {quadC() + 2}; }
+    __host__ __device__ F4 u() const { return {quadC() + 3}; }
+    __host__ __device__ F4 dx() const { return {quadD()}; }        // incoming direction
+    __host__ __device__ F4 dy() const { return {quadD() + 1}; }
+    __host__ __device__ F4 dz() const { return {quadD() + 2}; }
+    __host__ __device__ F4 v() const { return {quadD() + 3}; }
     // logical field k of slot j, in the order the debug capture hands them out: point, direction, colour, normal, u, v
     __host__ __device__ float fieldAt(int k, size_t j) const {
         if (k < 3) return q[j * 4 + k];
-        if (k < 6) return f[(size_t)(k - 3) * stride + j];
+        if (k < 6) return quadD()[j * 4 + (k - 3)];
         if (k < 9) return quadB()[j * 4 + (k - 6)];
-        return f[(size_t)(k - 6) * stride + j];
+        if (k < 12) return quadC()[j * 4 + (k - 9)];
+        return k == 12 ? quadC()[j * 4 + 3] : quadD()[j * 4 + 3];
     }
     __host__ __device__ int32_t *idx() const { return i; }     // stage key (see stage_key) or -1
     // the chunk-local sorted index a workgroup leaves in its tail (see "local move" in k_bounce): entry e of the chunk's region is
@@ -163,7 +165,7 @@ constexpr int SOA_FLOATS = 16, SOA_INTS = 3, SOA_LOGICAL_FLOATS = 14;      // wo
 __device__ __forceinline__ int32_t stage_key(int bin, int r_all, int r_scat) { return (int32_t)((uint32_t)bin | ((uint32_t)r_all << BIN_BITS) | ((uint32_t)r_scat << (BIN_BITS + RANK_BITS))); }
 
 __device__ __forceinline__ PathSoA soa_offset(PathSoA s, size_t off) {
-    s.q += 4 * off; s.f += off; s.i += off;
+    s.q += 4 * off; s.i += off;
     return s;
 }
 // The same stream, but with a stride the optimiser cannot see through: field addresses derived from the result are
@@ -811,12 +813,10 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const quad A = ld_u(reinterpret_cast<const quad *>(in.quadA()), j16), B = ld_u(reinterpret_cast<const quad *>(in.quadB()), j16);
         r.f[0] = A.x; r.f[1] = A.y; r.f[2] = A.z; r.pix = __float_as_int(A.w);
         r.f[6] = B.x; r.f[7] = B.y; r.f[8] = B.z; r.mg = __float_as_int(B.w);
-        r.f[3] = r.f[4] = r.f[5] = 0.f;
-        if (with_dir) { r.f[3] = ld_u(in.dx(), j4); r.f[4] = ld_u(in.dy(), j4); r.f[5] = ld_u(in.dz(), j4); }
-        r.f[9] = r.f[10] = r.f[11] = 0.f;
-        if (!coded_n) { r.f[9] = ld_u(in.nx(), j4); r.f[10] = ld_u(in.ny(), j4); r.f[11] = ld_u(in.nz(), j4); }
-        r.f[12] = r.f[13] = 0.f;
-        if (p.uses_uv) { r.f[12] = ld_u(in.u(), j4); r.f[13] = ld_u(in.v(), j4); }
+        r.f[3] = r.f[4] = r.f[5] = 0.f; r.f[9] = r.f[10] = r.f[11] = 0.f; r.f[12] = r.f[13] = 0.f;
+        // (texcoords matter on OBJ geoms only, whose records have both a normal and a direction: where a part is not read they are the 0 it would hold)
+        if (with_dir) { const quad D = ld_u(reinterpret_cast<const quad *>(in.quadD()), j16); r.f[3] = D.x; r.f[4] = D.y; r.f[5] = D.z; if (p.uses_uv) r.f[13] = D.w; }
+        if (!coded_n) { const quad C = ld_u(reinterpret_cast<const quad *>(in.quadC()), j16); r.f[9] = C.x; r.f[10] = C.y; r.f[11] = C.z; if (p.uses_uv) r.f[12] = C.w; }
         if (coded_n) {      // the cube's tabulated normal, the words decodeKey took it from (the tile path: the tables are staged)
             const vec3 n = cubeNormalByCode(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, r.mg >> 16, (r.pix >> 28) & 7);
             r.f[9] = n.x; r.f[10] = n.y; r.f[11] = n.z;
@@ -1192,9 +1192,16 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 B.x = rf[6 * TILE + tid]; B.y = rf[7 * TILE + tid]; B.z = rf[8 * TILE + tid]; B.w = rf[15 * TILE + tid];
                 st_u(reinterpret_cast<quad *>(stage.quadA()), gi16, A);
                 st_u(reinterpret_cast<quad *>(stage.quadB()), gi16, B);
-                if (with_dir) { st_u(stage.dx(), gi4, rf[3 * TILE + tid]); st_u(stage.dy(), gi4, rf[4 * TILE + tid]); st_u(stage.dz(), gi4, rf[5 * TILE + tid]); }
-                if (!coded_n) { st_u(stage.nx(), gi4, rf[9 * TILE + tid]); st_u(stage.ny(), gi4, rf[10 * TILE + tid]); st_u(stage.nz(), gi4, rf[11 * TILE + tid]); }
-                if (p.uses_uv) { st_u(stage.u(), gi4, rf[12 * TILE + tid]); st_u(stage.v(), gi4, rf[13 * TILE + tid]); }
+                if (with_dir) {
+                    quad D;
+                    D.x = rf[3 * TILE + tid]; D.y = rf[4 * TILE + tid]; D.z = rf[5 * TILE + tid]; D.w = p.uses_uv ? rf[13 * TILE + tid] : 0.f;
+                    st_u(reinterpret_cast<quad *>(stage.quadD()), gi16, D);
+                }
+                if (!coded_n) {
+                    quad C;
+                    C.x = rf[9 * TILE + tid]; C.y = rf[10 * TILE + tid]; C.z = rf[11 * TILE + tid]; C.w = p.uses_uv ? rf[12 * TILE + tid] : 0.f;
+                    st_u(reinterpret_cast<quad *>(stage.quadC()), gi16, C);
+                }
                 st_u(stage.idx(), gi4, skey);
             } else {
                 st_u(stage.idx(), gi4, (int32_t)-1);
@@ -1862,11 +1869,11 @@ namespace {
 
 // field arrays of `stride` elements each (stride = segments x cap: segment s of a field starts at s*cap)
 void carve(PathSoA &s, float *f, int32_t *i, size_t stride) {
-    s.q = f; s.f = f + 8 * stride; s.i = i; s.stride = (uint32_t)stride;
+    s.q = f; s.i = i; s.stride = (uint32_t)stride;
 }
 
 PathSoA soa_shift(PathSoA s, size_t off) {       // host side of soa_offset: the same fields `off` elements further
-    s.q += 4 * off; s.f += off; s.i += off;
+    s.q += 4 * off; s.i += off;
     return s;
 }
 
