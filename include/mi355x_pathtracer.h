@@ -260,6 +260,8 @@ int ptx_debug_tile_geoms(const ptx_camera *camera, int ngeoms, const float *boxe
  * the device, for n corner boxes (lo xyz, hi xyz): 8 floats per box = centre xyz, 0, half extent xyz, 0.  The CPU tests check that it
  * contains the corner box and that the device's slab arithmetic on it never rejects a ray that reaches the corner box. */
 int ptx_debug_cull_boxes(int n, const float *boxes6, float *centre_half8);
+/* Debug: workgroups of the specialised later-bounce kernel that fit a CU with lds_bytes of dynamic LDS each (0: what this tracer launches). */
+int ptx_debug_bounce_occupancy(ptx_tracer *t, int lds_bytes);
 /* Debug capture: the sorted stream of paths that will be shaded at bounce+1, as it stands after the given bounce
  * of the next iteration(s). */
 int ptx_debug_set_capture(ptx_tracer *t, int bounce);   /* -1 = off */

@@ -75,8 +75,8 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #define PT_PARK_STATE 1       // specialised unsplit k_bounce: state that is idle during the pair tests waits in LDS, not in registers
 #endif
 #ifndef PT_FAST_WAVES
-#define PT_FAST_WAVES 7       // waves per SIMD the specialised k_bounce variants are compiled for (<= 72 registers; 7 workgroups'
-                              // LDS is also what a CU holds with the Cornell tables)
+#define PT_FAST_WAVES 8       // waves per SIMD the specialised k_bounce variants are compiled for (<= 64 registers; 8 workgroups'
+                              // LDS is also what a CU holds with the Cornell tables since the record buffer lost a row and the window half its runs)
 #endif
 #ifndef PT_FAST_WAVES_SPLIT
 #define PT_FAST_WAVES_SPLIT 4 // same for the specialised MODE 1 variant, which carries the mesh candidate queue as well
@@ -95,7 +95,8 @@ static_assert(TILE <= 512 && (TILE & (TILE - 1)) == 0, "tile size: a power of tw
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
 // tileIntersect's 2 x 4 list counters
 // + the window over the input's run tables (locate): 65 start positions, 65 stream-index bases, 64 local-index bases, next run
-constexpr int WIN = 64, WIN_WORDS = 2 * (WIN + 1) + WIN + 2;
+constexpr int WIN = 32, WIN_WORDS = 2 * (WIN + 1) + WIN + 2;      // (a power of two <= 64: one wave loads a window; 32 since round 4 -- with the
+                                                                 // record rows below what lets EIGHT workgroups' LDS fit a CU for the Cornell tables)
 constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8 + WIN_WORDS) + 3) & ~3; }
 // k_bounce's dynamic LDS, in words: [scene tables][head][17 x TILE records].  The record buffer doubles as tileIntersect's
 // scratch, whose 64-bit minimum keys (best[], at word 6*TILE of it) are the target of ds_min_u64: a 4-byte-misaligned
@@ -103,6 +104,10 @@ constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8 + 
 // 2*WAVES*nb + 4*nb + 1 words put the records on an odd word, group_seg_size 20596 B = 5149 words).  Hence every part is a
 // multiple of 4 words, the layout has this one definition for host and device, and the asserts below pin it.
 constexpr int REC_WORDS = 17 * TILE;
+// (the specialised fused kernel carries no texcoords: its pixel / material / key rows move up over one of their two, 16 rows -- what
+// tileIntersect's scratch with the parked state needs anyway)
+constexpr int REC_ROWS_FAST0 = 16;
+static_assert(WIN <= 64 && (WIN & (WIN - 1)) == 0, "window of runs: one wave, binary search");
 __host__ __device__ constexpr size_t bounceLdsWords(int tableWords, int nb) { return (size_t)tableWords + (size_t)ldsHeadWords(nb) + REC_WORDS; }
 static_assert(ldsHeadWords(1) % 4 == 0 && ldsHeadWords(2) % 4 == 0 && ldsHeadWords(3) % 4 == 0 && ldsHeadWords(7) % 4 == 0 &&
               ldsHeadWords(45) % 4 == 0 && ldsHeadWords(65535) % 4 == 0, "record buffer must start 16-byte aligned");
@@ -598,12 +603,14 @@ __device__ __forceinline__ int scanFind8(const int32_t *cs, const int32_t *ca, i
 __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, int chunk_cap, int nruns, int r0, int gs0, int ga0, int lane) {
     const int r = r0 + lane;
     int ca = 0, cs = 0, cb = 0;
-    if (r < nruns) { ca = chunk[r]; cs = chunk[chunk_cap + r]; cb = chunk[2 * chunk_cap + r]; }
+    if (r < nruns && lane < WIN) { ca = chunk[r]; cs = chunk[chunk_cap + r]; cb = chunk[2 * chunk_cap + r]; }
     const int is = waveInclusiveScan(cs, lane), ia = waveInclusiveScan(ca, lane);
-    win[lane] = gs0 + is - cs;
-    win[WIN + 1 + lane] = ga0 + ia - ca;
-    win[2 * (WIN + 1) + lane] = cb;
-    if (lane == 63) { win[WIN] = gs0 + is; win[2 * WIN + 1] = ga0 + ia; win[2 * (WIN + 1) + WIN] = r0 + WIN; }
+    if (lane < WIN) {
+        win[lane] = gs0 + is - cs;
+        win[WIN + 1 + lane] = ga0 + ia - ca;
+        win[2 * (WIN + 1) + lane] = cb;
+    }
+    if (lane == WIN - 1) { win[WIN] = gs0 + is; win[2 * WIN + 1] = ga0 + ia; win[2 * (WIN + 1) + WIN] = r0 + WIN; }
 }
 
 // One bounce.  FIRST: generate camera rays; otherwise shade the stored paths of the previous bounce.
@@ -640,7 +647,8 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
 // FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
-__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {
+__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : FIRST ? PT_FAST_WAVES - 1 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {      // (the camera-ray
+                                                                                   // variant needs 65 registers: seven waves without spilling)
 #ifdef PT_WGCLOCK
     const unsigned long long wg_t0 = wall_clock64();       // 100 MHz: latency of the workgroup's phases (prologue, tile loop, tail)
 #endif
@@ -666,6 +674,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     int tq = 0;
     int32_t *rec = lds + ldsHeadWords(nb);                  // [17][TILE] record transpose buffer / tileIntersect scratch,
                                                                     // 16-byte aligned (64-bit LDS atomics live in it)
+    constexpr int R_PIX = (FAST && MODE == 0 ? REC_ROWS_FAST0 : 17) - 3, R_MG = R_PIX + 1, R_KEY = R_PIX + 2;      // rows of the record buffer (12 floats, [u, v,] these)
     uint32_t *qbuf = reinterpret_cast<uint32_t *>(rec + REC_WORDS);   // MODE 1: LDS stage of the queue of parked rays, [QCAP], kept
     int32_t *qcnt = rec + REC_WORDS + QCAP, *qbase = qcnt + 1;        // across tiles (so not inside the record buffer)
     if (MODE == 1 && tid == 0) *qcnt = 0;
@@ -1170,9 +1179,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             const bool coded_n = ntab_some && ((p.ntab_bins >> bin) & 1ull);
             if (!coded_n) { rf[9 * TILE + slot] = hit.n.x; rf[10 * TILE + slot] = hit.n.y; rf[11 * TILE + slot] = hit.n.z; }
             if (p.uses_uv) { rf[12 * TILE + slot] = hit.u; rf[13 * TILE + slot] = hit.v; }
-            rec[14 * TILE + slot] = coded_n ? (pix | (hit.ncode << 28)) : pix;
-            rec[15 * TILE + slot] = hit.mat | (hit.geom << 16);
-            rec[16 * TILE + slot] = stage_key(bin, r_all, r_scat);
+            rec[R_PIX * TILE + slot] = coded_n ? (pix | (hit.ncode << 28)) : pix;
+            rec[R_MG * TILE + slot] = hit.mat | (hit.geom << 16);
+            rec[R_KEY * TILE + slot] = stage_key(bin, r_all, r_scat);
         }
         __syncthreads();
         {
@@ -1181,15 +1190,15 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             const uint32_t gi4 = (uint32_t)(tile * TILE + tid) << 2;
             if (tid < npend) {
                 const float *rf = reinterpret_cast<const float *>(rec);
-                const int32_t skey = rec[16 * TILE + tid];
+                const int32_t skey = rec[R_KEY * TILE + tid];
                 // (this slot's record carries a direction iff its bin says so: the reader decides by the same bins, from the sorted position)
                 const bool with_dir = !dir_some || ((p.dir_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
                 const bool coded_n = ntab_some && ((p.ntab_bins >> (skey & ((1 << BIN_BITS) - 1))) & 1ull);
                 typedef float quad __attribute__((ext_vector_type(4)));
                 const uint32_t gi16 = gi4 << 2;
                 quad A, B;
-                A.x = rf[0 * TILE + tid]; A.y = rf[1 * TILE + tid]; A.z = rf[2 * TILE + tid]; A.w = rf[14 * TILE + tid];
-                B.x = rf[6 * TILE + tid]; B.y = rf[7 * TILE + tid]; B.z = rf[8 * TILE + tid]; B.w = rf[15 * TILE + tid];
+                A.x = rf[0 * TILE + tid]; A.y = rf[1 * TILE + tid]; A.z = rf[2 * TILE + tid]; A.w = rf[R_PIX * TILE + tid];
+                B.x = rf[6 * TILE + tid]; B.y = rf[7 * TILE + tid]; B.z = rf[8 * TILE + tid]; B.w = rf[R_MG * TILE + tid];
                 st_u(reinterpret_cast<quad *>(stage.quadA()), gi16, A);
                 st_u(reinterpret_cast<quad *>(stage.quadB()), gi16, B);
                 if (with_dir) {
@@ -1776,6 +1785,7 @@ struct ptx_tracer {
     int nbins = 1, nmats = 0, ngeoms = 0, maxTiles = 0, grid = 0, grid_seg = 0, cap = 0, cus = 0;
     bool grid_forced = false;                  // PTX_DEBUG_WG_PER_CU given: the grid is what it says for every kernel
     int dbg_mesh_wg_per_cu = 0;                 // PTX_DEBUG_MESH_WG_PER_CU: workgroups per CU of k_mesh's grid (tuning experiments)
+    int dbg_extra_lds = 0;
     int dbg_total_wg_per_cu = 0, dbg_nsets = 0; // PTX_DEBUG_TOTAL_WG_PER_CU / PTX_DEBUG_NSETS: tuning experiments (grid of a whole launch; sets of a short run)
     // device memory
     DGeom *d_geoms = nullptr; DMaterial *d_mats = nullptr; float *d_faces = nullptr; uint8_t *d_texels = nullptr;
@@ -2115,7 +2125,7 @@ const char *fast_violation(const ptx_tracer *t, int mode, bool first, bool needs
 
 template <bool FIRST, int MODE>
 void launch_bounce_variant(bool fast, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
-    if (fast) hipLaunchKernelGGL((k_bounce<FIRST, MODE, true>), grid, dim3(TILE), lds, stream, bp);
+    if (fast) hipLaunchKernelGGL((k_bounce<FIRST, MODE, true>), grid, dim3(TILE), lds - (MODE == 0 ? sizeof(int32_t) * (17 - REC_ROWS_FAST0) * TILE : 0), stream, bp);
     else hipLaunchKernelGGL((k_bounce<FIRST, MODE, false>), grid, dim3(TILE), lds, stream, bp);
 }
 // the one launch site of k_bounce: picks the variant by the predicate above
@@ -2150,7 +2160,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const int nb = t->nbins;
     const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
     const int triWords = t->tri_lds ? sceneTableWords(ntri_lds, t->nmats, t->ngeoms) : 0;
-    const size_t lds_bounce = sizeof(int32_t) * (bounceLdsWords(triWords, nb) + (t->split_mesh ? QUEUE_WORDS : 0));
+    const size_t lds_bounce = sizeof(int32_t) * (bounceLdsWords(triWords, nb) + (t->split_mesh ? QUEUE_WORDS : 0)) + (size_t)t->dbg_extra_lds;      // (+ PTX_DEBUG_EXTRA_LDS bytes: occupancy experiments)
     const bool cache_on = t->cache_active();
     const bool use_cache = cache_on && t->cache_valid && iter_first != 1;
     const bool fill_cache = cache_on && !use_cache;
@@ -2176,9 +2186,14 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     // each (gpurun_out/r4_c4wg*.log, r4_bouncewg*.log): C4 camera bounce alone 0.0365 (7 per CU) / 0.0338 (14) / 0.0320 (21) / 0.0300 ms
     // (28), later bounces 0.163 / 0.161 / 0.160 / 0.160 / 0.173 (42), wall of the 20-step run 0.176 / 0.172 / 0.173 / 0.173 / 0.179;
     // C5 (split bounce) 16 per CU 1.06-1.10, 32 1.03-1.07, 48 1.04-1.07 ms per iteration.
+    // End of round 4, after the records' diet (32 B instead of 56 for a wall hit, 16-byte quads) and with eight workgroups' LDS per CU: the
+    // later bounces as ONE round of the occupancy again (8 per CU) and the camera bounce 20 -- C4's 20-step run 0.147 -> 0.1425 ms per
+    // step, its long run 0.1415 -> 0.138 (three runs each of six plans on one box, gpurun_out/r4grid2.log; 28 / 14 was the choice while
+    // the kernels moved 40 % more bytes and a chunk's tail of index traffic was worth spreading).
     // (traced ahead of per-call requests: five per CU, so that two slots stay free for the caller's own short kernels)
     auto per_cu = [&](bool first_bounce) {
-        if (fast_unsplit) return defer ? PT_FAST_WAVES - 2 : first_bounce ? 28 : 14;
+        if (fast_unsplit && !defer) { if (const char *e = getenv(first_bounce ? "PTX_DEBUG_WG_FIRST" : "PTX_DEBUG_WG_LATER")) return std::max(1, atoi(e)); }      // tuning experiments
+        if (fast_unsplit) return defer ? PT_FAST_WAVES - 2 : first_bounce ? 20 : PT_FAST_WAVES;
         return t->split_mesh ? 32 : 8;
     };
     auto gx_of = [&](bool first_bounce) {
@@ -2753,6 +2768,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->force_fast = getenv("PTX_DEBUG_FORCE_FAST") != nullptr;
     if (const char *e = getenv("PTX_DEBUG_TOTAL_WG_PER_CU")) t->dbg_total_wg_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("PTX_DEBUG_NSETS")) t->dbg_nsets = std::max(0, atoi(e));
+    if (const char *e = getenv("PTX_DEBUG_EXTRA_LDS")) t->dbg_extra_lds = std::max(0, std::min(atoi(e), 32768)) & ~15;
     if (const char *e = getenv("PTX_DEBUG_MESH_WG_PER_CU")) t->dbg_mesh_wg_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("PTX_DEBUG_SPLIT_MIN")) t->split_min_paths = std::max(1LL, atoll(e));      // tuning experiments only
     if (t->lanes > 1) {
@@ -3425,6 +3441,19 @@ int ptx_debug_read_stamps(ptx_tracer *t, unsigned long long out48[48]) {
     }
     HIPCHECK(hipMemset(t->d_stamps, 0, sizeof(unsigned long long) * (48 + 2 * 64 * 4096 * 5)));
     return PTX_OK;
+}
+
+// Debug: how many workgroups of the specialised later-bounce kernel the runtime says fit a CU with `lds_bytes` of dynamic LDS each
+// (0 = what this tracer launches it with); negative = error.
+int ptx_debug_bounce_occupancy(ptx_tracer *t, int lds_bytes) {
+    if (!t) return -1;
+    if (hipSetDevice(t->device) != hipSuccess) return -1;
+    const int ntri_lds = t->split_mesh ? 0 : t->ntri_lds;
+    const int triWords = t->tri_lds ? sceneTableWords(ntri_lds, t->nmats, t->ngeoms) : 0;
+    size_t lds = lds_bytes > 0 ? (size_t)lds_bytes : sizeof(int32_t) * (bounceLdsWords(triWords, t->nbins) - (17 - REC_ROWS_FAST0) * TILE);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 0, true>, TILE, lds) != hipSuccess) return -2;
+    return n;
 }
 
 int ptx_debug_set_capture(ptx_tracer *t, int bounce) {
