@@ -36,19 +36,22 @@ CONTRACT_BYTES_BOUNCE_KERNEL = 76 + 120
 CONTRACT_BYTES_LOOP = 436
 
 
-def own_layout_bytes(rpb):
-    """Algorithmic bytes per ray of k_bounce (bounces >= 1) by THIS design's data layout, from the rays per bounce:
-    a ray entering bounce b reads its local-index entry (8 B) and its record (12 floats + slot + material|geom = 56 B); if it is
-    stored for bounce b + 1 it writes the 56-B record, its 4-B key and, in the kernel's tail, its 8-B local-index entry (re-reading the
-    key: 4 B); otherwise it writes 12 B of radiance and the 4-B empty key."""
+def own_layout_bytes(rpb, with_direction=1.0, with_normal=1.0):
+    """Algorithmic bytes per ray of k_bounce (bounces >= 1) by THIS design's data layout, from the rays per bounce and the
+    run's own record mix (ptx_stats: the share of stored paths whose record carries a direction / a normal rather than a 3-bit code):
+    a record is two 16-byte quads (shading point + pixel slot, throughput colour + material|geom), a third with the normal (+ texcoord u)
+    and a fourth with the incoming direction (+ texcoord v) where the next bounce can need them.  A ray entering bounce b reads its
+    local-index entry (8 B) and its record; if it is stored for bounce b + 1 it writes its record, its 4-B key and, in the kernel's tail,
+    its 8-B local-index entry (re-reading the key: 4 B); otherwise it writes 12 B of radiance and the 4-B empty key."""
     n = [float(x) for x in rpb] + [0.0]
     tot = sum(n[1:-1])
     if tot <= 0:
         return 0.0
+    rec = 32.0 + 16.0 * with_normal + 16.0 * with_direction
     b = 0.0
     for k in range(1, len(n) - 1):
         stored = n[k + 1]
-        b += n[k] * (8 + 56) + stored * (56 + 4 + 8 + 4) + (n[k] - stored) * (12 + 4)
+        b += n[k] * (8 + rec) + stored * (rec + 4 + 8 + 4) + (n[k] - stored) * (12 + 4)
     return b / tot
 
 
@@ -500,7 +503,11 @@ def main():
     else:
         units = rays_leg * (rpb[0] / max(sum(rpb), 1)) / max(dom_n, 1)
     avg_s = dom_ms / max(dom_n, 1) * 1e-3
-    own_bytes = own_layout_bytes(rpb) if dominant == "k_bounce" else 8.0 + 56 + 4 + 8 + 4      # (first bounce: nothing read, mostly stored)
+    sp = max(st2.get("stored_paths", 0) - st.get("stored_paths", 0), 0)
+    f_dir = (st2.get("stored_with_direction", 0) - st.get("stored_with_direction", 0)) / sp if sp else 1.0
+    f_nrm = 1.0 - (st2.get("stored_with_normal_code", 0) - st.get("stored_with_normal_code", 0)) / sp if sp else 1.0
+    rec_bytes = 32.0 + 16.0 * f_nrm + 16.0 * f_dir
+    own_bytes = own_layout_bytes(rpb, f_dir, f_nrm) if dominant == "k_bounce" else 8.0 + rec_bytes + 4 + 8 + 4      # (first bounce: nothing read, mostly stored)
     achieved = own_bytes * units / avg_s if avg_s > 0 else 0.0
     contract = CONTRACT_BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
     # HBM bytes and instruction counts per launch come from PMC counters, which need rocprofv3: they are NOT measured in this run but
@@ -567,13 +574,14 @@ def main():
     loop_contract = CONTRACT_BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
     # One read tells what bounds the kernel: `bound` names it (vector-instruction issue -- valu_issue.frac of the issue peak), achieved /
     # frac / traffic are the HBM side of the same launches by this design's own bytes; the contract's record sizes are under contract_*.
-    roofline = dict(schema="r3+: achieved / frac / algorithmic_bytes_per_unit are THIS design's own layout bytes (~120 B per ray); rounds 1-2 put the "
+    roofline = dict(schema="r3+: achieved / frac / algorithmic_bytes_per_unit are THIS design's own layout bytes (r3: ~120 B per ray; since the end of r4 ~85: records "
+                           "of 32-64 B by what the next bounce can need, record_bytes); rounds 1-2 put the "
                            "contract's 196 B there, which now lives under contract_196B_frac -- BENCH_r02's frac compares with contract_196B_frac, not with frac",
                     measured_in_this_run=["achieved", "frac", "avg_launch_us", "launches", "units_per_launch", "kernels_ms_per_step", "contract_*", "loop_ms_per_step"],
                     from_committed_profiles=["traffic", "traffic_over_algorithmic", "physical_frac", "valu_issue", "bound"], profiles=profiles_stale,
                     bound="valu" if valu_issue and valu_issue["frac"] > achieved / HBM_PEAK else "hbm", kernel=dominant,
                     achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
-                    algorithmic_bytes_per_unit=own_bytes, traffic=traffic, traffic_source=traffic_source,
+                    algorithmic_bytes_per_unit=own_bytes, record_bytes=dict(mean=rec_bytes, with_direction=f_dir, with_normal=f_nrm), traffic=traffic, traffic_source=traffic_source,
                     traffic_over_algorithmic=(traffic / (own_bytes * units)) if traffic and own_bytes else None,
                     physical_frac=(traffic / avg_s / HBM_PEAK) if traffic and avg_s > 0 else None,
                     valu_issue=valu_issue,

@@ -113,6 +113,9 @@ typedef struct ptx_stats {
     int64_t fenced;                  /* indices from internal tables (mesh-search queue, sort index) that the kernels found out of
                                         range and skipped or clamped instead of faulting, since create/reset.  Always 0: anything else
                                         means corrupted internal state (and a wrong pixel somewhere) -- report it                      */
+    int64_t stored_paths;            /* paths stored for a next bounce since create/reset, and how many of their records carry ...        */
+    int64_t stored_with_direction;   /* ... the incoming direction (reflective / refractive materials, materials of OBJ geoms: 16 B more) */
+    int64_t stored_with_normal_code; /* ... a 3-bit code instead of the normal (materials only cubes have: 16 B less)                      */
 } ptx_stats;
 
 typedef struct ptx_tracer ptx_tracer;     /* opaque: one scene on one device */

@@ -70,7 +70,8 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("bounces", C.c_int32), ("rays_per_bounce", C.c_int64 * 64), ("rays_total", C.c_int64),
-                ("loop_ms_total", C.c_double), ("iterations", C.c_int64), ("fenced", C.c_int64)]
+                ("loop_ms_total", C.c_double), ("iterations", C.c_int64), ("fenced", C.c_int64),
+                ("stored_paths", C.c_int64), ("stored_with_direction", C.c_int64), ("stored_with_normal_code", C.c_int64)]
 
 
 def debug_tile_geoms(camera, boxes6, depth_of_field=False, tile=None):
@@ -445,7 +446,8 @@ class MultiTracer:
         s = Stats()
         _check(self.lib.ptx_multi_get_stats(self.h, C.byref(s)), "ptx_multi_get_stats")
         return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
-                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced))
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced), stored_paths=int(s.stored_paths),
+                    stored_with_direction=int(s.stored_with_direction), stored_with_normal_code=int(s.stored_with_normal_code))
 
 
 class Tracer:
@@ -648,7 +650,8 @@ class Tracer:
         s = Stats()
         _check(self.lib.ptx_get_stats(self.h, C.byref(s)), "ptx_get_stats")
         return dict(bounces=s.bounces, rays_per_bounce=[int(s.rays_per_bounce[b]) for b in range(min(s.bounces, 64))],
-                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced))
+                    rays_total=int(s.rays_total), loop_ms_total=float(s.loop_ms_total), iterations=int(s.iterations), fenced=int(s.fenced), stored_paths=int(s.stored_paths),
+                    stored_with_direction=int(s.stored_with_direction), stored_with_normal_code=int(s.stored_with_normal_code))
 
     # --- per-stage entry points used by the parity tests --------------------------------------------------
     def geom_test(self, gi, rays):

@@ -1566,21 +1566,32 @@ __global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const 
 // per-iteration statistics: rays entering the intersect stage of each bounce = sum of totals_all[bounce]
 // (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced)
 __global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int nseg, size_t seg_totals,
-                        int64_t *last, int64_t *total) {
+                        int64_t *last, int64_t *total, unsigned long long dir_bins, unsigned long long ntab_bins, int64_t *kinds) {
     // one wave: lane j takes the (segment, bounce) pairs j, j + 64, ...
     if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-    long long sum = 0;
+    long long sum = 0, st = 0, sd = 0, sn = 0;      // rays; stored paths: all, with a direction, with a normal code (what the records weigh)
     for (int k = threadIdx.x; k < nseg * nbounces; k += 64) {
         const int sg = k / nbounces, b = k - sg * nbounces;
         long long s = 0;
         if (!(b == 0 && skip_first))
-            for (int q = 0; q < nbins; q++) s += totals[seg_totals * sg + (size_t)b * stride + q];
+            for (int q = 0; q < nbins; q++) {
+                s += totals[seg_totals * sg + (size_t)b * stride + q];
+                const long long c = totals[seg_totals * sg + (size_t)b * stride + nbins + q];
+                st += c;
+                if (nbins > 64 || ((dir_bins >> q) & 1ull)) sd += c;
+                if (nbins <= 64 && ((ntab_bins >> q) & 1ull)) sn += c;
+            }
         if (sg == nseg - 1 && b < 64) last[b] = s;      // per-bounce counts of the last iteration of the batch
         sum += s;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(total), (unsigned long long)sum);
+    for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); st += __shfl_xor(st, off); sd += __shfl_xor(sd, off); sn += __shfl_xor(sn, off); }
+    if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(total), (unsigned long long)sum);
+        atomicAdd(reinterpret_cast<unsigned long long *>(kinds), (unsigned long long)st);
+        atomicAdd(reinterpret_cast<unsigned long long *>(kinds + 1), (unsigned long long)sd);
+        atomicAdd(reinterpret_cast<unsigned long long *>(kinds + 2), (unsigned long long)sn);
+    }
 }
 
 // sendImageToPBO, src/pathtrace.cu:69-89
@@ -1847,7 +1858,7 @@ struct ptx_tracer {
     float *d_part = nullptr;                             // [kmax][W*H*3] per-iteration radiance (batched mode)
     int32_t *d_cache_totals = nullptr;                   // [2][nbins] of bounce 0 (cache)
     int32_t *d_emit_count = nullptr, *d_emit_pix = nullptr; float *d_emit_rgb = nullptr;
-    int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total, [65] = fenced indices (BounceParams::fenced)
+    int64_t *d_stats = nullptr;                          // [64] last iteration, [64] = running total, [65] = fenced indices (BounceParams::fenced), [66..68] = stored paths: all, with direction, with normal code
     uint32_t fence_slots = 0;                            // = cap; PTX_DEBUG_FENCE_SLOTS lowers it (test of the counter: entries beyond it are fenced)
     int maxBounces = 0;
     bool cache_valid = false;
@@ -2351,7 +2362,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
                            t->seg_part, t->d_part + seg0 * t->seg_part, t->d_image);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, t->d_totals + seg0 * seg_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, K,
-                       seg_totals, t->d_stats, t->d_stats + 64);
+                       seg_totals, t->d_stats, t->d_stats + 64, t->dir_bins, t->ntab_bins, t->d_stats + 66);
     if (t->lanes > 1) HIPCHECK(hipEventRecord(t->ev_chain[lane], stream));
     HIPCHECK(hipGetLastError());
     t->iterations += K;
@@ -2409,7 +2420,7 @@ int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
     hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, 1,
                        seg_part, t->d_part + sg * seg_part, t->d_image);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals + sg * t->seg_totals, t->nbins, t->traceDepth, 2 * t->nbins,
-                       a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64);
+                       a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64, t->dir_bins, t->ntab_bins, t->d_stats + 66);
     HIPCHECK(hipGetLastError());
     t->iterations += 1;
     return PTX_OK;
@@ -2865,8 +2876,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
 #endif
     HC(hipMalloc(&t->d_tile_geoms, sizeof(uint32_t) * (size_t)std::max(t->maxTiles, 1)));
     if (update_tile_geoms(t) != PTX_OK) return fail(PTX_ERR_HIP);
-    HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 66));
-    HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 66));
+    HC(hipMalloc(&t->d_stats, sizeof(int64_t) * 69));
+    HC(hipMemset(t->d_stats, 0, sizeof(int64_t) * 69));
     t->fence_slots = (uint32_t)t->cap;
     if (const char *e = getenv("PTX_DEBUG_FENCE_SLOTS")) t->fence_slots = (uint32_t)std::min<long long>(t->cap, std::max<long long>(1, atoll(e)));      // tests only
 #undef HC
@@ -2907,7 +2918,7 @@ int ptx_reset_image(ptx_tracer *t) {
     if (!t) return set_error(PTX_ERR_INVALID, "null tracer");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipMemsetAsync(t->d_image, 0, sizeof(float) * 3 * (size_t)t->cam.resx * t->cam.resy, t->stream));
-    HIPCHECK(hipMemsetAsync(t->d_stats, 0, sizeof(int64_t) * 66, t->stream));
+    HIPCHECK(hipMemsetAsync(t->d_stats, 0, sizeof(int64_t) * 69, t->stream));
     t->iterations = 0; t->loop_ms_total = 0.0; t->cache_valid = false;
     return PTX_OK;
 }
@@ -3147,13 +3158,14 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out) {
     if (!t || !out) return set_error(PTX_ERR_INVALID, "null argument");
     HIPCHECK(hipSetDevice(t->device));
     HIPCHECK(hipStreamSynchronize(t->stream));
-    int64_t h[66];
+    int64_t h[69];
     HIPCHECK(hipMemcpy(h, t->d_stats, sizeof h, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->bounces = t->traceDepth;
     for (int b = 0; b < 64 && b < t->traceDepth; b++) out->rays_per_bounce[b] = h[b];
     out->rays_total = h[64];
     out->fenced = h[65];
+    out->stored_paths = h[66]; out->stored_with_direction = h[67]; out->stored_with_normal_code = h[68];
     for (int l = 1; l < MAX_LANES; l++) ahead_fold_time(t, l);
     out->loop_ms_total = t->loop_ms_total + (t->last_ahead_lane >= 0 ? 0.0 : ptx_last_loop_ms(t));
     out->iterations = t->iterations;

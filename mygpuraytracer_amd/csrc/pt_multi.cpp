@@ -274,6 +274,7 @@ int ptx_multi_get_stats(ptx_multi *m, ptx_stats *out) {
         for (int b = 0; b < 64; b++) out->rays_per_bounce[b] += s.rays_per_bounce[b];
         out->rays_total += s.rays_total;
         out->fenced += s.fenced;
+        out->stored_paths += s.stored_paths; out->stored_with_direction += s.stored_with_direction; out->stored_with_normal_code += s.stored_with_normal_code;
         if (s.loop_ms_total > out->loop_ms_total) out->loop_ms_total = s.loop_ms_total;
         if (i == 0) out->iterations = s.iterations;
     }

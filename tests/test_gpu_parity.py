@@ -307,10 +307,23 @@ def test_records_without_their_direction_lose_nothing_else(gpu_product, O, monke
     n, paths, isects = oracle_pending_stream(O, 1, 0)
     need = records_with_direction(d, isects["materialId"][isects["t"] > 0])
     assert need.any() and (~need).any() and records_with_normal_code(d, isects["materialId"][isects["t"] > 0]).any()
+    # ptx_stats counts the stored paths by what their records weigh: the oracle's streams of iteration 1, bounce by bounce
+    want = np.zeros(3, np.int64)
+    for b in range(depth - 1):
+        n, paths, isects = oracle_pending_stream(O, 1, b)
+        pend = (isects["t"] > 0) & (d["materials"][isects["materialId"], 10] <= 0)
+        m = isects["materialId"][pend]
+        want += (len(m), int(records_with_direction(d, m).sum()), int(records_with_normal_code(d, m).sum()))
+    with gpu_product.Tracer(s, **opt) as T3:
+        T3.render(1, 1)
+        st = T3.stats()
+        assert (st["stored_paths"], st["stored_with_direction"], st["stored_with_normal_code"]) == tuple(int(x) for x in want)
     monkeypatch.setenv("PTX_DEBUG_NO_DIR_SKIP", "1")
     with gpu_product.Tracer(s, **opt) as T2:
         T2.render(1, 6)
         assert beq(T2.read_image(), img)
+        st = T2.stats()
+        assert st["stored_with_direction"] == st["stored_paths"] > 0 and st["stored_with_normal_code"] == 0
 
 
 def test_cottage_mesh_from_vectors_on_device(gpu_product, O):
