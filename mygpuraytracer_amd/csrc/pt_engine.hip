@@ -693,7 +693,11 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     const int32_t *in_totals = FIRST ? nullptr : p.in_totals + p.seg_in_totals * seg;
     const int32_t *in_chunk = FIRST ? nullptr : p.in_chunk + p.seg_in_chunk * seg;
     const int in_nruns = nb * p.in_gx;
-    const int n_in = FIRST ? p.tm.owned : sum_totals(in_totals + nb, nb);
+    // the input's stored paths per bin: lane b of every wave holds bin b's (ONE load instead of a chain of scalar ones -- a small launch's
+    // workgroup lives 30 us, and this prologue is a third of it); more than 64 bins: the scalar loop
+    int v_tot = 0;
+    if (!FIRST && nb <= 64 && lane < nb) v_tot = in_totals[nb + lane];
+    const int n_in = FIRST ? p.tm.owned : nb <= 64 ? __builtin_amdgcn_readlane(waveInclusiveScan(v_tot, lane), 63) : sum_totals(in_totals + nb, nb);
     const int ntiles = (n_in + TILE - 1) / TILE;
     // every workgroup owns a contiguous chunk of tiles, so that the prefix of a tile is (prefix of its chunk) +
     // (running sum inside the chunk) and no separate scan pass over the tiles is needed
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         int lo[2] = {0, 0}, hi[2] = {0, 0}, nr = 0, pos = 0;
         bool open = false;
         for (int b = 0; b < nb; b++) {
-            const int tot = in_totals[nb + b];
+            const int tot = __builtin_amdgcn_readlane(v_tot, b);      // (masks are only in use with <= 64 bins)
             if (tot > 0) {
                 const bool set = (mask >> b) & 1ull;
                 if (set && !open) { if (nr < 2) lo[nr] = pos; open = true; }
