@@ -1226,6 +1226,50 @@ def test_edge_ragged_sizes_and_depths(gpu_product, O, res, depth):
     _vs_oracle(gpu_product, O, s, batch=1, sort_by_material=0)
 
 
+def test_record_masks_with_more_runs_than_the_reader_tells_apart(gpu_product, O, tmp_path, monkeypatch):
+    """The next bounce knows by sorted position which records carry a direction and which a normal code: two ranges of positions per
+    mask, so ptx_create keeps at most two runs of set bits in either (dir_bins: gaps filled, ntab_bins: runs dropped).  Materials laid
+    out so that both rules have three and more runs before that -- diffuse cubes, specular spheres, glass, a specular cube and a diffuse
+    sphere alternating -- and some bins empty at some bounces: frames and ray counts equal the oracle's, with the masks, without them,
+    one iteration per launch set, and with the sort off (one bin: every record complete)."""
+    kinds = [("cube", 0, 0, 0, 5), ("cube", 0, 0, 0, 0), ("sphere", 1, 0, 0, 0), ("cube", 0, 0, 0, 0), ("sphere", 0, 1, 1.5, 0),
+             ("cube", 0, 0, 0, 0), ("cube", 1, 0, 0, 0), ("sphere", 0, 0, 0, 0), ("cube", 0, 0, 0, 0), ("sphere", 0, 1, 1.3, 0), ("cube", 0, 0, 0, 0)]
+    rng = np.random.default_rng(21)
+    text = ""
+    for m, (_, refl, refr, ior, emit) in enumerate(kinds):
+        rgb = rng.uniform(0.3, 0.95, 3)
+        text += MAT % ((m,) + tuple(rgb) + tuple(rgb[::-1]) + (refl, refr, ior, emit))
+    text += CAMERA_BLOCK
+    text += "OBJECT 0\ncube\nmaterial 0\nTRANS 0 10 0\nROTAT 0 0 0\nSCALE 8 .3 8\n\n"
+    text += "OBJECT 1\ncube\nmaterial 1\nTRANS 0 0 0\nROTAT 0 0 0\nSCALE 12 .01 12\n\n"
+    text += "OBJECT 2\ncube\nmaterial 3\nTRANS 0 5 -5\nROTAT 0 90 0\nSCALE .01 10 10\n\n"
+    k = 3
+    for m, (typ, *_r) in enumerate(kinds):
+        if m in (0, 1, 3):
+            continue
+        for _ in range(2):
+            pos = rng.uniform([-4, 0.8, -4], [4, 8, 2]); rot = rng.uniform(0, 90, 3); sc = rng.uniform(0.8, 2.2, 3)
+            text += "OBJECT %d\n%s\nmaterial %d\nTRANS %g %g %g\nROTAT %g %g %g\nSCALE %g %g %g\n\n" % ((k, typ, m) + tuple(pos) + tuple(rot) + tuple(sc))
+            k += 1
+    s = _scene_from_text(gpu_product, text, tmp_path, res=(160, 120), depth=7)
+    d = s.dump()
+    mats = np.arange(len(kinds))
+    need, coded = records_with_direction(d, mats), records_with_normal_code(d, mats)
+    runs = lambda b: int(np.sum(b & ~np.concatenate([[False], b[:-1]])))
+    assert runs(need) >= 3 and runs(coded) >= 3                       # what the rules ask for, before ptx_create trims them
+    img = _vs_oracle(gpu_product, O, s, iters=4)
+    _vs_oracle(gpu_product, O, s, iters=3, batch=1)
+    _vs_oracle(gpu_product, O, s, iters=2, sort_by_material=0)
+    with gpu_product.Tracer(s) as T:
+        T.render(1, 4)
+        st = T.stats()
+        assert 0 < st["stored_with_normal_code"] < st["stored_paths"] and 0 < st["stored_with_direction"] < st["stored_paths"]
+    monkeypatch.setenv("PTX_DEBUG_NO_DIR_SKIP", "1")
+    with gpu_product.Tracer(s) as T:
+        T.render(1, 4)
+        assert beq(T.read_image(), img)
+
+
 def test_edge_many_materials(gpu_product, O, tmp_path):
     """More material bins (70) than lanes in a wave, mirrors / glass / lights / diffuse interleaved, rotated and scaled
     cubes and spheres: the per-bin ranking, the chunk prefixes and the segment bases all get exercised."""
