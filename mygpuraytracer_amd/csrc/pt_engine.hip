@@ -263,6 +263,7 @@ struct BounceParams {
     int32_t uses_uv;                       // some OBJ geom has a texture: texcoords are carried, otherwise not
     unsigned long long dir_bins;           // bit b: the records of material bin b carry the incoming direction (reflective, refractive, or a
                                            // material of an OBJ geom: what scatterRay reads it for); the other bins' records do not
+    unsigned long long in_dir_bins, in_ntab_bins;      // dir_bins / ntab_bins of the launch that wrote `in` (the same, unless `in` is the cached camera bounce)
     unsigned long long ntab_bins;          // bit b: every hit of material bin b is a cube hit (no sphere or OBJ geom has the material): its records
                                            // carry the 3-bit code of the cube's tabulated normal in pix's bits 28-30 instead of the normal
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
@@ -729,8 +730,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     const bool ntab_some = masks_on && p.ntab_bins != 0ull;       // parks keep their direction -- k_mesh walks with it -- whatever their bin turns out to be)
     int dir_lo0 = 0, dir_len0 = 0x7fffffff, dir_lo1 = 0, dir_len1 = 0;      // sorted positions whose records carry a direction: all, unless ...
     int ntab_lo0 = 0, ntab_len0 = 0, ntab_lo1 = 0, ntab_len1 = 0;           // ... whose records carry a normal code instead of a normal: none, unless ...
-    if (!FIRST && dir_some) binRanges(p.dir_bins, dir_lo0, dir_len0, dir_lo1, dir_len1);
-    if (!FIRST && ntab_some) binRanges(p.ntab_bins, ntab_lo0, ntab_len0, ntab_lo1, ntab_len1);
+    if (!FIRST && masks_on && p.in_dir_bins != ~0ull) binRanges(p.in_dir_bins, dir_lo0, dir_len0, dir_lo1, dir_len1);
+    if (!FIRST && masks_on && p.in_ntab_bins != 0ull) binRanges(p.in_ntab_bins, ntab_lo0, ntab_len0, ntab_lo1, ntab_len1);
 #ifdef PT_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t0, st_t1;
 #define STAMP(k) do { st_t1 = __builtin_amdgcn_s_memtime(); st_acc[k] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
@@ -1855,6 +1856,7 @@ struct ptx_tracer {
     int uses_uv = 0;
     unsigned long long dir_bins = ~0ull;                 // BounceParams::dir_bins (all ones: every record carries its direction)
     unsigned long long ntab_bins = 0ull;                 // BounceParams::ntab_bins (none: every record carries its normal)
+    unsigned long long cache_dir_bins = ~0ull, cache_ntab_bins = 0ull;      // ... as the cached camera bounce was written
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
@@ -2299,6 +2301,9 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
         bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? ~0ull : t->dir_bins;
         bp.ntab_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? 0ull : t->ntab_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
+        // (the masks tell the READER of a stage what its records hold; a launch that WRITES with other masks than it reads with -- a cached
+        // camera bounce replayed while a debug capture has switched them off, or the other way round -- gets both: in_* for what it reads)
+        bp.in_dir_bins = from_cache ? t->cache_dir_bins : bp.dir_bins; bp.in_ntab_bins = from_cache ? t->cache_ntab_bins : bp.ntab_bins;
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
         bp.chunk = to_cache ? t->d_cache_chunk : chunks(b); bp.chunk_cap = (int32_t)chunk_cap;
@@ -2344,6 +2349,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cache_super, supers(0, 0), sizeof(int32_t) * 2 * nb * t->nsuper, hipMemcpyDeviceToDevice, stream));
             t->cache_gx = gx_b;
+            t->cache_dir_bins = bp.dir_bins; t->cache_ntab_bins = bp.ntab_bins;
             t->cache_valid = true;
         }
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)

@@ -1226,6 +1226,29 @@ def test_edge_ragged_sizes_and_depths(gpu_product, O, res, depth):
     _vs_oracle(gpu_product, O, s, batch=1, sort_by_material=0)
 
 
+def test_capture_after_the_camera_bounce_was_cached(gpu_product, O):
+    """A debug capture switches the record masks off for its own launches; the cached camera bounce it replays was written with them on.
+    The bounce that reads the cache must read it the way it was written: iterations 1-3 fill and use the cache, iteration 4 is captured
+    after bounce 1 -- the stream equals the oracle's, field by field."""
+    s, T = make_pair(gpu_product, O, "cornell.txt", (96, 72), 8, antialiasing=0)
+    d = s.dump()
+    T.render(1, 3)
+    T.debug_capture(1)
+    T.pathtrace(4)
+    g = T.debug_stream()
+    n, paths, isects = oracle_pending_stream(O, 4, 1)
+    pend = (isects["t"] > 0) & (d["materials"][isects["materialId"], 10] <= 0)
+    assert len(g["pix"]) == int(pend.sum()) > 100
+    assert beq(g["pix"], paths["pixelIndex"][pend]) and beq(g["mat"], isects["materialId"][pend])
+    for k, nm in enumerate(("dx", "dy", "dz")):
+        assert beq(g[nm], paths["direction"][pend][:, k])
+    for k, nm in enumerate(("nx", "ny", "nz")):
+        assert beq(g[nm], isects["normal"][pend][:, k])
+    for k, nm in enumerate(("cr", "cg", "cb")):
+        assert beq(g[nm], paths["color"][pend][:, k])
+    T.close()
+
+
 def test_record_masks_with_more_runs_than_the_reader_tells_apart(gpu_product, O, tmp_path, monkeypatch):
     """The next bounce knows by sorted position which records carry a direction and which a normal code: two ranges of positions per
     mask, so ptx_create keeps at most two runs of set bits in either (dir_bins: gaps filled, ntab_bins: runs dropped).  Materials laid
