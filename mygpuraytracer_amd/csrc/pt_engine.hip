@@ -836,6 +836,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             r.f[9] = n.x; r.f[10] = n.y; r.f[11] = n.z;
             r.pix &= 0x0fffffff;
         }
+        // (fence: the pixel slot becomes the address of the path's radiance when it ends -- found by a record read with other masks than
+        // it was written with, end of round 4: a normal code taken for part of the slot)
+        if (__builtin_expect((uint32_t)r.pix >= (uint32_t)p.tm.owned, 0)) { fence_report(p); r.pix = 0; }
     };
     auto classifyRay = [&](const Hit &hit, const PathState &ps, int pix, int &bin, bool &pending) {
         classifyPath<FIRST>(p, iter, part, batched, hit, ps.color, pix, bin, pending);
@@ -1482,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
             key = km < key ? km : key;
         }
         const int owner = st.mg()[sa], pix = st.pix()[sa];
-        if ((uint32_t)owner >= slots) { fence_report(p); continue; }
+        if ((uint32_t)owner >= slots || (uint32_t)pix >= (uint32_t)p.tm.owned) { fence_report(p); continue; }
         const vec3 color = V3(st.cr()[sa], st.cg()[sa], st.cb()[sa]);
         Hit hit;
         decodeKey(p.sc, p.sc.gtab, key, ray, p.uses_uv != 0, hit);
