@@ -227,13 +227,21 @@ def c5_per_iteration(pt, dev_index, iters=72):
     with pt.Tracer(s, depth_of_field=1, device=dev_index) as T:
         T.render(1, 36)
         T.synchronize()
-        r0 = T.stats()["rays_total"]
+        st0 = T.stats()
+        r0 = st0["rays_total"]
         t0 = time.perf_counter()
         T.render(100, iters)
         T.synchronize()
         dt = time.perf_counter() - t0
-        rays = T.stats()["rays_total"] - r0
-    return dt / iters * 1e3, rays / iters
+        st1 = T.stats()
+        rays = st1["rays_total"] - r0
+        sp = max(st1.get("stored_paths", 0) - st0.get("stored_paths", 0), 1)
+        mix = dict(with_direction=(st1.get("stored_with_direction", 0) - st0.get("stored_with_direction", 0)) / sp,
+                   with_normal=1.0 - (st1.get("stored_with_normal_code", 0) - st0.get("stored_with_normal_code", 0)) / sp)
+        mix["mean"] = 32.0 + 16.0 * mix["with_normal"] + 16.0 * mix["with_direction"]
+        # bounces >= 1 by the layout's own bytes (own_layout_bytes; the texcoords ride in the normal's and the direction's quads)
+        mix["algorithmic_bytes_per_ray_later_bounces"] = own_layout_bytes(st1["rays_per_bounce"], mix["with_direction"], mix["with_normal"])
+    return dt / iters * 1e3, rays / iters, mix
 
 
 def stream_compaction_device(torch, pt, device):
@@ -633,9 +641,9 @@ def main():
             out["dropin_per_call_ms"] = None
             out["dropin_per_call"] = dict(error=str(e)[:200])
         try:
-            c5_ms, c5_rays = c5_per_iteration(pt, dev_index)
+            c5_ms, c5_rays, c5_mix = c5_per_iteration(pt, dev_index)
             out["c5_ms_per_iteration"] = c5_ms
-            out["c5"] = dict(ms_per_iteration=c5_ms, rays_per_iteration=c5_rays, Mrays_per_s=c5_rays / c5_ms / 1e3,
+            out["c5"] = dict(ms_per_iteration=c5_ms, rays_per_iteration=c5_rays, Mrays_per_s=c5_rays / c5_ms / 1e3, record_bytes=c5_mix,
                              workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, 1 GPU, 72 iterations after 36 (BASELINE configs[4] / C5)")
         except Exception as e:
             out["c5_ms_per_iteration"] = None
