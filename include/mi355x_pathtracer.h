@@ -259,6 +259,12 @@ int ptx_kat_fast_exact(ptx_tracer *t, int64_t mismatches[3]);
  * row-tile split.  Returns the number of tiles, -1 on a bad argument.  The CPU tests check the superset property ray by ray. */
 int ptx_debug_tile_geoms(const ptx_camera *camera, int ngeoms, const float *boxes6, int depth_of_field, int tile_rows, int tile_rank,
                          int tile_world, uint32_t *masks_out, int max_tiles);
+/* CPU-only: which material bins' stored paths carry what: masks[0] bit b = records of bin b carry the incoming direction
+ * (reflective / refractive materials, materials of OBJ geoms), masks[1] bit b = they carry a 3-bit code instead of the normal (materials
+ * only cubes have); bin = nmaterials - 1 - material when sorting by material, else 0; at most two runs of set bits in either.
+ * geom_type: 0 sphere, 1 cube, 3 OBJ.  Returns 0, -1 on a bad argument (nmaterials 1..64). */
+int ptx_debug_record_masks(int nmaterials, const ptx_material *materials, int ngeoms, const int32_t *geom_type, const int32_t *geom_material,
+                           int sort_by_material, uint64_t masks[2]);
 /* CPU-only: the table the candidate pre-test (the conservative world boxes every ray is tested against before the exact tests) reads on
  * the device, for n corner boxes (lo xyz, hi xyz): 8 floats per box = centre xyz, 0, half extent xyz, 0.  The CPU tests check that it
  * contains the corner box and that the device's slab arithmetic on it never rejects a ray that reaches the corner box. */

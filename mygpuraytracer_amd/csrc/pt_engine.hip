@@ -1955,6 +1955,35 @@ void make_world_aabb(const DGeom &d, const std::vector<float> &faces, float out6
     }
 }
 
+// Which material bins' records must carry the incoming direction to the next bounce -- scatterRay (pt_device.h) reads it in its
+// reflective and refractive branches and for every hit on an OBJ geom (Schlick's cosine), never for a diffuse cube or sphere hit --
+// and which bins' hits are all cube hits (the material is on cubes only): their records carry a code for the cube's tabulated normal
+// instead of the normal.  The next bounce tells the kinds of record apart by sorted position, at most two ranges each, so a mask keeps
+// at most two runs of set bits: gaps between the runs of the first are FILLED (a direction more is harmless), runs beyond the second
+// of the other are CLEARED.  nmaterials <= 64 bins (bin = nmaterials - 1 - material when sorting, else one bin).
+void record_masks(int nmaterials, const DMaterial *mats, int ngeoms, const int *geom_type, const int *geom_material, bool sort,
+                  unsigned long long &dir_bins, unsigned long long &ntab_bins) {
+    unsigned long long need = 0, cubes = 0;
+    const int nbins = sort ? nmaterials : 1;
+    for (int m = 0; m < nmaterials; m++) {
+        bool nd = mats[m].hasReflective > 0 || mats[m].hasRefractive > 0, on_cube = false, on_other = false;
+        for (int i = 0; i < ngeoms; i++)
+            if (geom_material[i] == m) { nd = nd || geom_type[i] == G_OBJ; (geom_type[i] == G_CUBE ? on_cube : on_other) = true; }
+        const int b = sort ? nmaterials - 1 - m : 0;
+        if (nd) need |= 1ull << b;
+        if (on_cube && !on_other && sort) cubes |= 1ull << b;
+    }
+    auto runs = [&](unsigned long long mask) { int n = 0; for (int b = 0; b < nbins; b++) n += ((mask >> b) & 1) && !(b && ((mask >> (b - 1)) & 1)); return n; };
+    while (runs(need) > 2) {                          // fill the gap behind the first run
+        int b = 0;
+        while (!((need >> b) & 1)) b++;
+        while ((need >> b) & 1) b++;
+        need |= 1ull << b;
+    }
+    while (runs(cubes) > 2) cubes &= ~(1ull << (63 - __builtin_clzll(cubes)));      // drop the highest set bin
+    dir_bins = need; ntab_bins = cubes;
+}
+
 // The same box as the device's candidate pre-test reads it (cullMask): centre and half extent.  The half extent grows by what the two
 // roundings can lose (half an ulp of the centre, half an ulp of itself) and then some; an unbounded box is centre 0, half extent inf.
 void world_box_centre_half(const float lohi8[8], float out8[8]) {
@@ -2697,30 +2726,14 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     std::vector<DMaterial> hm((size_t)std::max(nmaterials, 1));
     static_assert(sizeof(DMaterial) == sizeof(ptx_material), "material layout");
     if (nmaterials) memcpy(hm.data(), materials, sizeof(DMaterial) * (size_t)nmaterials);
-    {   // which material bins' records must carry the incoming direction to the next bounce: scatterRay (pt_device.h) reads it in its
-        // reflective and refractive branches and for every hit on an OBJ geom (Schlick's cosine), never for a diffuse cube or sphere hit;
-        // and which bins' hits are all cube hits (the material is on cubes only): their records carry a code for the cube's tabulated
-        // normal instead of the normal.  The next bounce tells the two kinds of record apart by sorted position -- at most two ranges
-        // each -- so a mask keeps at most two runs of set bits: gaps between the runs of the first are FILLED (a direction more is
-        // harmless), runs beyond the second of the other are CLEARED.
-        unsigned long long need = 0, cubes = 0;
+    {   // which records carry what (record_masks); off: more than 64 bins, no material, or PTX_DEBUG_NO_DIR_SKIP
+        unsigned long long need = ~0ull, cubes = 0ull;
         const bool off = t->nbins > 64 || nmaterials < 1 || getenv("PTX_DEBUG_NO_DIR_SKIP") != nullptr;
-        for (int m = 0; m < nmaterials && !off; m++) {
-            bool nd = hm[m].hasReflective > 0 || hm[m].hasRefractive > 0, on_cube = false, on_other = false;
-            for (int i = 0; i < ngeoms; i++)
-                if (hg[i].materialid == m) { nd = nd || hg[i].type == G_OBJ; (hg[i].type == G_CUBE ? on_cube : on_other) = true; }
-            const int b = opt.sort_by_material ? nmaterials - 1 - m : 0;
-            if (nd) need |= 1ull << b;
-            if (on_cube && !on_other && opt.sort_by_material) cubes |= 1ull << b;
+        if (!off) {
+            std::vector<int> gt((size_t)ngeoms), gm((size_t)ngeoms);
+            for (int i = 0; i < ngeoms; i++) { gt[i] = hg[i].type; gm[i] = hg[i].materialid; }
+            record_masks(nmaterials, hm.data(), ngeoms, gt.data(), gm.data(), opt.sort_by_material != 0, need, cubes);
         }
-        auto runs = [&](unsigned long long mask) { int n = 0; for (int b = 0; b < t->nbins; b++) n += ((mask >> b) & 1) && !(b && ((mask >> (b - 1)) & 1)); return n; };
-        while (runs(need) > 2) {                          // fill the gap behind the first run
-            int b = 0;
-            while (!((need >> b) & 1)) b++;
-            while ((need >> b) & 1) b++;
-            need |= 1ull << b;
-        }
-        while (runs(cubes) > 2) cubes &= ~(1ull << (63 - __builtin_clzll(cubes)));      // drop the highest set bin
         t->dir_bins = off ? ~0ull : need;
         // (the code rides in bits 28-30 of the pixel slot; the tabulated normals are what the tile path's decodeKey reads)
         t->ntab_bins = (off || !t->cull || t->tm.owned >= (1 << 28) || getenv("PTX_DEBUG_NO_NORMAL_CODES")) ? 0ull : cubes;
@@ -3405,6 +3418,19 @@ int ptx_debug_bvh_check(const float *faces15, int nfaces, const float *rays6, in
 }
 
 // node visits of the last ptx_debug_bvh_check: skip-link walk, front-to-back binary walk, four-wide walk (nodes), wide stack need,
+// CPU-only: ptx_create's rule for what a stored path's record carries (record_masks), for nmaterials <= 64 materials and ngeoms geoms
+// given by type and material: masks[0] = dir_bins, masks[1] = ntab_bins (before the conditions of a particular tracer: candidate masks
+// on, fewer than 2^28 owned pixels).
+int ptx_debug_record_masks(int nmaterials, const ptx_material *materials, int ngeoms, const int32_t *geom_type, const int32_t *geom_material,
+                           int sort_by_material, uint64_t masks[2]) {
+    if (nmaterials < 1 || nmaterials > 64 || !materials || ngeoms < 0 || (ngeoms && (!geom_type || !geom_material)) || !masks)
+    { set_error(PTX_ERR_INVALID, "ptx_debug_record_masks: bad argument"); return -1; }
+    unsigned long long d = 0, n = 0;
+    record_masks(nmaterials, reinterpret_cast<const DMaterial *>(materials), ngeoms, geom_type, geom_material, sort_by_material != 0, d, n);
+    masks[0] = d; masks[1] = n;
+    return 0;
+}
+
 // CPU-only: the candidate pre-test's table (world_box_centre_half) for n corner boxes (lo xyz, hi xyz): 8 floats each = centre xyz, 0,
 // half extent xyz, 0 -- what cullMask reads on the device.
 int ptx_debug_cull_boxes(int n, const float *boxes6, float *centre_half8) {
