@@ -95,7 +95,10 @@ static_assert(TILE <= 512 && (TILE & (TILE - 1)) == 0, "tile size: a power of tw
 // words of per-tile LDS in front of the 16-byte aligned record buffer: ranking histogram, running prefix, tile counts/offsets,
 // tileIntersect's 2 x 4 list counters
 // + the window over the input's run tables (locate): 65 start positions, 65 stream-index bases, 64 local-index bases, next run
-constexpr int WIN = 32, WIN_WORDS = 2 * (WIN + 1) + WIN + 2;      // (a power of two <= 64: one wave loads a window; 32 since round 4 -- with the
+#ifndef PT_WIN
+#define PT_WIN 32
+#endif
+constexpr int WIN = PT_WIN, WIN_WORDS = 2 * (WIN + 1) + WIN + 2;      // (a power of two <= 64: one wave loads a window; 32 since round 4 -- with the
                                                                  // record rows below what lets EIGHT workgroups' LDS fit a CU for the Cornell tables)
 constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8 + WIN_WORDS) + 3) & ~3; }
 // k_bounce's dynamic LDS, in words: [scene tables][head][17 x TILE records].  The record buffer doubles as tileIntersect's
@@ -106,7 +109,10 @@ constexpr int ldsHeadWords(int nb) { return ((2 * WAVES * nb + 4 * nb + 1 + 8 + 
 constexpr int REC_WORDS = 17 * TILE;
 // (the specialised fused kernel carries no texcoords: its pixel / material / key rows move up over one of their two, 16 rows -- what
 // tileIntersect's scratch with the parked state needs anyway)
-constexpr int REC_ROWS_FAST0 = 16;
+#ifndef PT_REC_ROWS_FAST0
+#define PT_REC_ROWS_FAST0 16
+#endif
+constexpr int REC_ROWS_FAST0 = PT_REC_ROWS_FAST0;
 static_assert(WIN <= 64 && (WIN & (WIN - 1)) == 0, "window of runs: one wave, binary search");
 __host__ __device__ constexpr size_t bounceLdsWords(int tableWords, int nb) { return (size_t)tableWords + (size_t)ldsHeadWords(nb) + REC_WORDS; }
 static_assert(ldsHeadWords(1) % 4 == 0 && ldsHeadWords(2) % 4 == 0 && ldsHeadWords(3) % 4 == 0 && ldsHeadWords(7) % 4 == 0 &&
