@@ -425,20 +425,38 @@ def main():
     # ---- N > 1 only, OUTSIDE the timed region, same JSON line: what a single short scaling run cannot say by itself -------------
     multi = None
     if dist_on and not by_iter:
+        # (multigpu.all_ok / agreed_phase / RankFailed: every rank's verdict on a phase it ran LOCALLY, agreed on by all -- a failure of
+        # one rank is then every rank's failure at the same point; tests/test_multigpu_gloo.py runs the protocol with 2 gloo ranks)
+        flag_dev = device if args.backend == "nccl" else None
+        all_ok = lambda ok: multigpu.all_ok(ok, flag_dev)
+        RankFailed = multigpu.RankFailed
+
         def timed_tile_run(tracer, img, res, first, count, how=None):
-            """`count` steps of this rank's tile + the exchange, bracketed like the timed region; max over ranks."""
-            r0 = tracer.stats()["rays_total"]
+            """`count` steps of this rank's tile + the exchange, bracketed like the timed region; max over ranks.  The rank-local part
+            (the render) may fail on one rank: that rank still walks through every collective below, then all ranks raise together."""
+            err = None
+            r0 = n = 0
             barrier()
             a = time.perf_counter()
-            tracer.render(first, count)
-            tracer.synchronize()
+            try:
+                r0 = tracer.stats()["rays_total"]
+                tracer.render(first, count)
+                tracer.synchronize()
+            except Exception as e:
+                err = e
             b = time.perf_counter() - a
             reduce_frame(img, res, how)
             barrier()
             c = time.perf_counter() - a
-            n = tracer.stats()["rays_total"] - r0
-            return (float(all_reduce_scalar(c, torch.float64, dist.ReduceOp.MAX)), float(all_reduce_scalar(b, torch.float64, dist.ReduceOp.MAX)),
-                    int(all_reduce_scalar(n, torch.int64, dist.ReduceOp.SUM)))
+            try:
+                n = tracer.stats()["rays_total"] - r0
+            except Exception as e:
+                err = err or e
+            out = (float(all_reduce_scalar(c, torch.float64, dist.ReduceOp.MAX)), float(all_reduce_scalar(b, torch.float64, dist.ReduceOp.MAX)),
+                   int(all_reduce_scalar(n, torch.int64, dist.ReduceOp.SUM)))
+            if not all_ok(err is None):
+                raise RankFailed("rank %d: %s" % (rank, err) if err else "another rank failed in the render of this leg")
+            return out
 
         def exchange_alone(img, res, how, reps=5):
             """the exchange by itself on the buffers of the run (median of `reps`; max over ranks): barrier, exchange, barrier"""
@@ -467,33 +485,65 @@ def main():
                                              "frame it owns to rank 0, reduce = RCCL reduce(SUM) of the zero-padded full frames (north_star's spelling): same frame bit for bit")
         del scratch
         # (c) BASELINE configs[4] as it is named: the 3840x2160 textured-mesh scene with depth of field on N ranks, its exchange included
-        try:
+        # Every phase that can fail on ONE rank (the assets on rank 0, a tracer's hipMalloc at 4K, the warm-up render) runs rank-locally
+        # under its own try, and the ranks agree on its outcome (all_ok) BEFORE the next collective: either all ranks go on or all skip
+        # the leg and the line carries c5.error -- no rank is left waiting in a barrier / reduce for one that has moved on to the
+        # roofline leg (round 4's version ran the collectives inside a rank-local try; its first 8-GPU run could have hung there).
+        C5RES, C5STEPS = (3840, 2160), 72
+        T5 = img5 = warm5 = None
+        c5_err = None
+
+        def c5_phase(fn):
+            """run fn() locally, agree on the outcome; returns True if every rank got through"""
+            nonlocal c5_err
+            ok, msg = multigpu.agreed_phase(fn, flag_dev)
+            if not ok and c5_err is None:
+                c5_err = msg
+            return ok
+
+        def c5_assets():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from conftest import ensure_standin_assets
             if rank == 0:
                 ensure_standin_assets()
-            barrier()
-            C5RES, C5STEPS = (3840, 2160), 72
+
+        def c5_create():
+            nonlocal T5, img5, warm5
             s5 = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=C5RES, depth=8)
             s5.apply_runcuda_camera()
             img5 = multigpu.frame_buffer(C5RES[0], C5RES[1], world, device)
+            warm5 = img5.clone()
             torch.cuda.current_stream(device).synchronize()
             kw5 = dict(device=dev_index, lanes=args.lanes, depth_of_field=1)
             if world > 1:
                 kw5.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
-            with pt.Tracer(s5, external_image_ptr=img5.data_ptr(), **kw5) as T5:
-                T5.render(1, 36)
-                T5.synchronize()
-                reduce_frame(img5.clone(), C5RES)
-                ct, cr, crays = timed_tile_run(T5, img5, C5RES, 100, C5STEPS)
+            T5 = pt.Tracer(s5, external_image_ptr=img5.data_ptr(), **kw5)
+
+        def c5_warm():
+            T5.render(1, 36)
+            T5.synchronize()
+
+        try:
+            # (all_ok is itself a barrier: after c5_assets every rank sees rank 0's files)
+            if c5_phase(c5_assets) and c5_phase(c5_create) and c5_phase(c5_warm):
+                reduce_frame(warm5, C5RES)          # warm the exchange at this size (every rank is here: agreed above)
+                ct, cr, crays = timed_tile_run(T5, img5, C5RES, 100, C5STEPS)      # raises on ALL ranks if one failed
                 multi["c5"] = dict(ms_per_iteration=ct / C5STEPS * 1e3, steps=C5STEPS, rays_per_iteration=crays / C5STEPS, Mrays_per_s=crays / ct / 1e6,
                                    slowest_rank_render_ms=cr * 1e3, exchange_and_barrier_ms=(ct - cr) * 1e3, exchange=args.exchange,
                                    frame_MB=C5RES[0] * C5RES[1] * 12 / 1e6, fenced=T5.stats()["fenced"],
                                    workload="cornellSpaceship20k.txt 3840x2160 depth 8, AA + DoF, textured 20448-triangle BVH mesh, %d row-tile ranks + 1 %s/run "
                                             "(BASELINE configs[4] / C5; speed-up = the N = 1 line's c5_ms_per_iteration / this)" % (world, args.exchange))
-            del img5
-        except Exception as e:
+            else:
+                multi["c5"] = dict(error=c5_err)
+        except RankFailed as e:                     # (raised by every rank at the same point: no collective is pending)
             multi["c5"] = dict(error=str(e)[:300])
+        finally:
+            if T5 is not None:
+                try:
+                    T5.close()
+                except Exception:
+                    pass
+            del img5, warm5
 
     # roofline leg: the same K steps again with hipEvents around every launch (on the tracer's stream)
     T.set_kernel_timing(True)

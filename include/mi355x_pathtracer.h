@@ -30,6 +30,16 @@
 extern "C" {
 #endif
 
+/* ABI revision of this header: bumped whenever a struct a caller allocates (ptx_options, ptx_stats, ptx_camera ...) grows or an entry
+ * point changes meaning.  A caller compiled against one revision and loaded against a library of another must not hand it those
+ * structs: check ptx_abi_version() == PTX_ABI_VERSION after loading (mygpuraytracer_amd/api.py does, and refuses), or use the sized
+ * entry points (ptx_get_stats_sized), which never write more than the caller says it has.
+ * 5 = round 5: ptx_options.arith; ptx_stats as of round 4 (fenced, stored_*).  Libraries before 5 do not export ptx_abi_version. */
+#define PTX_ABI_VERSION 5
+int ptx_abi_version(void);
+size_t ptx_sizeof_options(void);           /* sizeof(ptx_options) / sizeof(ptx_stats) as the LIBRARY was compiled */
+size_t ptx_sizeof_stats(void);
+
 #define PTX_OK 0
 #define PTX_ERR_INVALID 1      /* bad argument / malformed scene                      */
 #define PTX_ERR_IO 2           /* file could not be read                              */
@@ -102,7 +112,16 @@ typedef struct ptx_options {
     int32_t lanes;               /* launch sets in flight, each on a stream of its own: 0 = default (3), 1 .. 8 explicit  */
     int32_t no_mesh_split;       /* 1 = meshes are searched inside the bounce kernel even when they have a BVH; 0 = scenes
                                     with BVH meshes run the mesh search as a kernel of its own between two halves of it   */
+    int32_t arith;               /* 0 = EXACT (default, and what every headline number is measured with): fp32 without contraction,
+                                    IEEE division and square root, own correctly rounded sin/cos -- bit-identical to the CPU
+                                    oracle.  1 = CONTRACTED: the same kernels compiled as a second code object with fused
+                                    multiply-adds and the hardware's reciprocal / square-root / sine instructions, i.e. the kind
+                                    of arithmetic the reference's real build runs (nvcc contracts by default); results agree with
+                                    EXACT within the statistical fp32 tolerance of DESIGN.md section 3 (tests/test_fp_tolerance.py),
+                                    not bit for bit.  PTX_ERR_UNSUPPORTED if the library was built without that code object.  */
 } ptx_options;
+#define PTX_ARITH_EXACT 0
+#define PTX_ARITH_CONTRACTED 1
 
 typedef struct ptx_stats {
     int32_t bounces;                 /* bounce-loop passes of the last iteration                       */
@@ -199,6 +218,9 @@ int ptx_write_pbo(ptx_tracer *t, int iter, uint8_t *host_rgba);          /* send
 int ptx_write_pbo_device(ptx_tracer *t, int iter, void *device_uchar4);
 double ptx_last_loop_ms(ptx_tracer *t);                 /* timer(): bounce loop of the last iteration       */
 int ptx_get_stats(ptx_tracer *t, ptx_stats *out);
+/* the same, writing at most out_bytes of the struct (a caller compiled against an older, shorter ptx_stats passes ITS sizeof;
+ * fields past the library's own struct are zeroed) */
+int ptx_get_stats_sized(ptx_tracer *t, void *out, size_t out_bytes);
 int ptx_owned_pixels(const ptx_tracer *t);              /* pixels this tracer generates (tile split)        */
 void *ptx_stream(ptx_tracer *t);
 /* ---- N GPUs of one node, one process (csrc/pt_multi.cpp) ---------------------------------------------------------

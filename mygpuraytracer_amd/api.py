@@ -23,11 +23,17 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmi355x_pathtracer.so")
 # A/B timing of variant builds (tools/ab_*.sh): PTX_AB_LIBRARY names another build of the SAME library to load instead, so that the
-# scripts no longer overwrite the in-tree product (an interrupted run used to leave a variant in its place).  Development only.
+# scripts no longer overwrite the in-tree product (an interrupted run used to leave a variant in its place).  Development only, and
+# behind a second switch: without PTX_DEV=1 the variable is REFUSED (round 4's one GPU fault came through this door -- a test run
+# against a stale variant build), so that neither a test run nor the driver can pick up anything but the in-tree product by accident.
 if os.environ.get("PTX_AB_LIBRARY"):
+    if os.environ.get("PTX_DEV") != "1":
+        raise ImportError("PTX_AB_LIBRARY is set (%s) without PTX_DEV=1: variant builds are loaded for A/B timing only; unset it or "
+                          "set PTX_DEV=1" % os.environ["PTX_AB_LIBRARY"])
     LIB_PATH = os.path.abspath(os.environ["PTX_AB_LIBRARY"])
 
 PTX_OK = 0
+ABI_VERSION = 5          # include/mi355x_pathtracer.h: PTX_ABI_VERSION
 vp = C.c_void_p
 
 
@@ -65,7 +71,7 @@ class Options(C.Structure):
     _fields_ = [("depth_of_field", C.c_int32), ("cache_first_bounce", C.c_int32), ("sort_by_material", C.c_int32),
                 ("antialiasing", C.c_int32), ("bounding_box", C.c_int32),
                 ("tile_rows", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("lanes", C.c_int32), ("no_mesh_split", C.c_int32)]
+                ("device", C.c_int32), ("batch", C.c_int32), ("no_lds_triangles", C.c_int32), ("apps_variant", C.c_int32), ("no_cull", C.c_int32), ("no_bvh", C.c_int32), ("lanes", C.c_int32), ("no_mesh_split", C.c_int32), ("arith", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -148,6 +154,15 @@ def load_library():
                               "(or make -C mygpuraytracer_amd/csrc). There is no CPU fallback." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     i, f = C.c_int, C.c_float
+    # the structs below are allocated HERE and filled by the library: a library of another ABI revision (an older variant build
+    # loaded for A/B timing) would overrun them or leave their tail unset -- refused, whatever it is
+    if not hasattr(L, "ptx_abi_version"):
+        raise PathTracerError("%s predates ptx_abi_version (ABI < %d): rebuild it from this tree" % (LIB_PATH, ABI_VERSION))
+    L.ptx_abi_version.restype = i
+    L.ptx_sizeof_options.restype = L.ptx_sizeof_stats.restype = C.c_size_t
+    if L.ptx_abi_version() != ABI_VERSION or L.ptx_sizeof_options() != C.sizeof(Options) or L.ptx_sizeof_stats() != C.sizeof(Stats):
+        raise PathTracerError("%s has ABI %d (options %d B, stats %d B), this module expects %d (%d B, %d B): rebuild the library" % (
+            LIB_PATH, L.ptx_abi_version(), L.ptx_sizeof_options(), L.ptx_sizeof_stats(), ABI_VERSION, C.sizeof(Options), C.sizeof(Stats)))
     L.ptx_last_error.restype = C.c_char_p
     L.ptx_device_count.restype = i
     L.ptx_default_options.argtypes = [C.POINTER(Options)]
@@ -193,6 +208,7 @@ def load_library():
     L.ptx_write_pbo_device.restype, L.ptx_write_pbo_device.argtypes = i, [vp, i, vp]
     L.ptx_last_loop_ms.restype, L.ptx_last_loop_ms.argtypes = C.c_double, [vp]
     L.ptx_get_stats.restype, L.ptx_get_stats.argtypes = i, [vp, C.POINTER(Stats)]
+    L.ptx_get_stats_sized.restype, L.ptx_get_stats_sized.argtypes = i, [vp, vp, C.c_size_t]
     L.ptx_owned_pixels.restype, L.ptx_owned_pixels.argtypes = i, [vp]
     L.ptx_stream.restype, L.ptx_stream.argtypes = vp, [vp]
     L.ptx_set_kernel_timing.restype, L.ptx_set_kernel_timing.argtypes = i, [vp, i]

@@ -7,7 +7,7 @@
 //   * a workgroup (512 threads for the scan, 1024 for compaction) takes the next 16384-element tile (ticket from an
 //     atomic counter, so a tile's predecessors are always resident or done), loaded as coalesced non-temporal
 //     16-byte loads, 8 or 4 per lane;
-//   * scan inside the tile: 4 per lane per load in registers, wave scan by __shfl_up, the 64 (load, wave) totals
+//   * scan inside the tile: 4 per lane per load in registers, wave scan in DPP (round 5; __shfl_up before), the 64 (load, wave) totals
 //     scanned by wave 0 through LDS;
 //   * the tile publishes {flag, total} as one 8-byte word (relaxed agent-scope store: one granule, no fence needed,
 //     visible across the XCDs' L2s) and its wave 0 looks back over its predecessors' words, 64 per step, adding
@@ -48,20 +48,23 @@ thread_local float g_gpu_ms = 0.f, g_cpu_ms = 0.f;
 int sc_fail(const std::string &m) { ptx_internal_set_error(m.c_str()); return PTX_ERR_HIP; }
 #define SC_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return sc_fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+// inclusive prefix sum over the lanes of a wave in the vector ALU's own lane network (DPP), as pt_engine.hip's waveInclusiveScan: four
+// shifted adds inside the rows of 16 lanes, lane 15 of a row broadcast into the next row (rows 1 and 3), lane 31 into the upper half.
+// Six dependent vector instructions where __shfl_up made six ds_bpermute round trips through the LDS crossbar (rounds 1-4) -- at frame
+// sizes (2 M elements) the kernel is a chain of such latencies, not a stream.
 __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+// sum over the wave, in every lane: the scan's last lane through the scalar path (v_readlane), no LDS round trip
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_scan(v, 0), 63); }
 
 // kernMapToBoolean (common.cu:25-34): bools[i] = idata[i] != 0.  The first n4 quads go as 16-byte accesses (both arrays 16-byte
 // aligned), the rest one by one; HBM-bound, 8 B per element.
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(SC_THREADS, 4) void k_onepass(int n, const int *__r
         const int t = s_wtot[lane];
         const int ti = wave_inclusive_scan(t, lane);
         s_wtot[lane] = ti - t;
-        const int total = __shfl(ti, 63);
+        const int total = __builtin_amdgcn_readlane(ti, 63);
         int excl = 0;
         if (tile == 0) {
             if (lane == 0) __hip_atomic_store(&status[0], ST_INCLUSIVE | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
         }
     };
-    auto fetch = [&](uint32_t li4, int idx_base, InRec &r, int jp) {
+    auto fetch = [&](uint32_t li4, int idx_base, InRec &r, int jp) -> bool {
         const PathSoA in = soa_fresh(in_k);
         // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
         // slot of that bounce's stage and the path's rank inside its run
@@ -838,13 +838,17 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (with_dir) { const quad D = ld_u(reinterpret_cast<const quad *>(in.quadD()), j16); r.f[3] = D.x; r.f[4] = D.y; r.f[5] = D.z; if (p.uses_uv) r.f[13] = D.w; }
         if (!coded_n) { const quad C = ld_u(reinterpret_cast<const quad *>(in.quadC()), j16); r.f[9] = C.x; r.f[10] = C.y; r.f[11] = C.z; if (p.uses_uv) r.f[12] = C.w; }
         if (coded_n) {      // the cube's tabulated normal, the words decodeKey took it from (the tile path: the tables are staged)
-            const vec3 n = cubeNormalByCode(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, r.mg >> 16, (r.pix >> 28) & 7);
+            // (the geom index comes out of the same untrusted record as the pixel slot below: clamped before it indexes the tables)
+            const int g = (int)min((uint32_t)(r.mg >> 16), (uint32_t)(p.sc.ngeoms - 1));
+            const vec3 n = cubeNormalByCode(p.sc, reinterpret_cast<const float *>(pt_lds) + p.sc.ntri_lds * 24 + p.sc.nmats * 11, g, (r.pix >> 28) & 7);
             r.f[9] = n.x; r.f[10] = n.y; r.f[11] = n.z;
             r.pix &= 0x0fffffff;
         }
         // (fence: the pixel slot becomes the address of the path's radiance when it ends -- found by a record read with other masks than
-        // it was written with, end of round 4: a normal code taken for part of the slot)
-        if (__builtin_expect((uint32_t)r.pix >= (uint32_t)p.tm.owned, 0)) { fence_report(p); r.pix = 0; }
+        // it was written with, end of round 4: a normal code taken for part of the slot.  A fenced record is a DEAD path, as in k_finish:
+        // it is counted, and it neither scatters nor adds light to a pixel that is not its own)
+        if (__builtin_expect((uint32_t)r.pix >= (uint32_t)p.tm.owned, 0)) { fence_report(p); r.pix = 0; return false; }
+        return true;
     };
     auto classifyRay = [&](const Hit &hit, const PathState &ps, int pix, int &bin, bool &pending) {
         classifyPath<FIRST>(p, iter, part, batched, hit, ps.color, pix, bin, pending);
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 if (tile_subset != 0u) generateRay(p.cam, iter, p.traceDepth, p.aa != 0, p.dof != 0, x, y, ps);
             } else {
                 // shadeFakeMaterial for a path that is known to scatter (src/pathtrace.cu:391-394)
-                fetch(li4, idx_base, cur, min(i, n_in - 1));
+                const bool rec_ok = fetch(li4, idx_base, cur, min(i, n_in - 1));
                 const vec3 intersect = V3(cur.f[0], cur.f[1], cur.f[2]);           // stored as origin + t * direction
                 ps.d = V3(cur.f[3], cur.f[4], cur.f[5]);
                 ps.color = V3(cur.f[6], cur.f[7], cur.f[8]);
@@ -939,10 +943,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 Rng rng; rng.seed(iter, sidx, 0);
                 bool ended = (FAST && MODE == 0) ? scatterRay<false>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng)
                                                  : scatterRay<true>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
-                if (ended) {         // emissive texel: remainingBounces 1 -> 0, colour goes to the image
-                    deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps);
-                    alive = false;
-                }
+                if (ended && rec_ok) deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps);      // emissive texel: remainingBounces 1 -> 0, colour goes to the image
+                if (ended || !rec_ok) alive = false;
             }
         }
         STAMP(0);        // load + shade (or ray generation)
@@ -1578,7 +1580,9 @@ __global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const 
 }
 
 // per-iteration statistics: rays entering the intersect stage of each bounce = sum of totals_all[bounce]
-// (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced)
+// (bounce 0 is not counted on iterations that took it from the first-bounce cache: nothing was traced -- so the cached bounce-0 records
+// that every such iteration RE-READS are not part of stored_* either: the mix describes what was written, once.)
+// dir_bins / ntab_bins = the masks the batch's launches wrote with (enqueue_batch: batch_dir_bins), not the tracer's.
 __global__ void k_stats(const int32_t *totals, int nbins, int nbounces, int stride, int skip_first, int nseg, size_t seg_totals,
                         int64_t *last, int64_t *total, unsigned long long dir_bins, unsigned long long ntab_bins, int64_t *kinds) {
     // one wave: lane j takes the (segment, bounce) pairs j, j + 64, ...
@@ -1856,7 +1860,8 @@ struct ptx_tracer {
     // turns tracing the NEXT kmax iterations into their per-iteration radiance buffers while the caller works the current
     // batch off, one k_gather (+ k_stats) per call on the main stream.  What a call returns is unchanged: the image holds
     // exactly the iterations asked for so far, summed in the same order.
-    struct Ahead { int first = 0, count = 0, next = 0, unfolded = 0; bool use_cache = false, valid = false, timed = false; };
+    struct Ahead { int first = 0, count = 0, next = 0, unfolded = 0; bool use_cache = false, valid = false, timed = false;
+                   unsigned long long dir_bins = ~0ull, ntab_bins = 0ull; };      // (the record masks the batch was written with: k_stats)
     Ahead ahead[MAX_LANES];
     int ahead_cur = -1, ahead_nxt = -1;                  // lane whose batch is being consumed / lane holding the batch after it
     bool render_ahead = false;
@@ -2303,6 +2308,10 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     };
 #define KT(kind, launch) do { int rc_ = kt_begin(kind); if (rc_ != PTX_OK) return rc_; launch; rc_ = kt_end(); if (rc_ != PTX_OK) return rc_; } while (0)
     if (fill_cache) HIPCHECK(hipMemsetAsync(t->d_emit_count, 0, sizeof(int32_t), stream));
+    // what this batch's launches WRITE their records with (a debug capture switches the masks off for its own launches); k_stats weighs
+    // the batch's stored paths by these, not by the tracer's
+    const bool masks_off = t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP");
+    const unsigned long long batch_dir_bins = masks_off ? ~0ull : t->dir_bins, batch_ntab_bins = masks_off ? 0ull : t->ntab_bins;
     for (int b = 0; b < t->traceDepth; b++) {
         const bool first = b == 0;
         if (first && use_cache) {
@@ -2337,8 +2346,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.seg_in_totals = from_cache ? 0 : seg_totals; bp.seg_in_chunk = from_cache ? 0 : seg_chunk;
         bp.image = t->d_image;
         bp.iter = iter_first; bp.iter_stride = stride; bp.traceDepth = t->traceDepth; bp.bounce = b;
-        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? ~0ull : t->dir_bins;
-        bp.ntab_bins = (t->capture_bounce >= 0 && !getenv("PTX_DEBUG_KEEP_DIR_SKIP")) ? 0ull : t->ntab_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
+        bp.aa = t->opt.antialiasing; bp.dof = t->opt.depth_of_field; bp.sort = t->opt.sort_by_material; bp.uses_uv = t->uses_uv; bp.dir_bins = batch_dir_bins;
+        bp.ntab_bins = batch_ntab_bins; bp.apps = t->opt.apps_variant; bp.albedo = t->d_albedo;
         // (the masks tell the READER of a stage what its records hold; a launch that WRITES with other masks than it reads with -- a cached
         // camera bounce replayed while a debug capture has switched them off, or the other way round -- gets both: in_* for what it reads)
         bp.in_dir_bins = from_cache ? t->cache_dir_bins : bp.dir_bins; bp.in_ntab_bins = from_cache ? t->cache_ntab_bins : bp.ntab_bins;
@@ -2402,6 +2411,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     }
     if (defer) {                                     // render-ahead: gather and statistics follow per iteration (finish_segment)
         t->ahead[lane].use_cache = use_cache;
+        t->ahead[lane].dir_bins = batch_dir_bins; t->ahead[lane].ntab_bins = batch_ntab_bins;
         HIPCHECK(hipGetLastError());
         return PTX_OK;
     }
@@ -2410,7 +2420,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
                            t->seg_part, t->d_part + seg0 * t->seg_part, t->d_image);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, t->d_totals + seg0 * seg_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, K,
-                       seg_totals, t->d_stats, t->d_stats + 64, t->dir_bins, t->ntab_bins, t->d_stats + 66);
+                       seg_totals, t->d_stats, t->d_stats + 64, batch_dir_bins, batch_ntab_bins, t->d_stats + 66);
     if (t->lanes > 1) HIPCHECK(hipEventRecord(t->ev_chain[lane], stream));
     HIPCHECK(hipGetLastError());
     t->iterations += K;
@@ -2468,7 +2478,7 @@ int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
     hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, 1,
                        seg_part, t->d_part + sg * seg_part, t->d_image);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals + sg * t->seg_totals, t->nbins, t->traceDepth, 2 * t->nbins,
-                       a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64, t->dir_bins, t->ntab_bins, t->d_stats + 66);
+                       a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64, a.dir_bins, a.ntab_bins, t->d_stats + 66);
     HIPCHECK(hipGetLastError());
     t->iterations += 1;
     return PTX_OK;
@@ -2503,9 +2513,31 @@ void ptx_default_options(ptx_options *o) {
     o->tile_rows = 0; o->tile_rank = 0; o->tile_world = 1; o->device = -1; o->batch = 0; o->no_lds_triangles = 0; o->apps_variant = 0; o->no_cull = 0;
 }
 
+// (kmax_cap > 0: at most that many iterations per launch set, whatever the rule or the option says; *oom = an allocation failed for
+// want of memory and *kmax_used iterations per set were being allocated for)
+static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
+                         const ptx_camera *camera, int trace_depth, const ptx_options *options, float *external_image,
+                         void *stream, ptx_tracer **out, int kmax_cap, bool *oom, int *kmax_used);
+
 int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
                const ptx_camera *camera, int trace_depth, const ptx_options *options, float *external_image,
                void *stream, ptx_tracer **out) {
+    // an out-of-memory failure is retried with half the iterations per launch set (they only set how much is in flight, never what
+    // is computed) until one iteration per set does not fit either
+    int cap = 0;
+    for (;;) {
+        bool oom = false;
+        int used = 0;
+        const int rc = create_tracer(ngeoms, geoms, nmaterials, materials, camera, trace_depth, options, external_image, stream, out, cap, &oom, &used);
+        if (rc == PTX_OK || !oom || used <= 1) return rc;
+        (void)hipGetLastError();
+        cap = used / 2;
+    }
+}
+
+static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_material *materials,
+                         const ptx_camera *camera, int trace_depth, const ptx_options *options, float *external_image,
+                         void *stream, ptx_tracer **out, int kmax_cap, bool *oom, int *kmax_used) {
     if (!out) return set_error(PTX_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (ngeoms < 0 || nmaterials < 0 || (ngeoms && !geoms) || (nmaterials && !materials) || !camera)
@@ -2551,7 +2583,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
     t->maxBounces = trace_depth;
     hipDeviceProp_t prop;
     auto fail = [&](int code) { free_tracer(t); return code; };
-#define HC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(PTX_ERR_HIP); } } while (0)
+#define HC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (e_ == hipErrorOutOfMemory) *oom = true; set_error(PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); return fail(PTX_ERR_HIP); } } while (0)
     HC(hipGetDeviceProperties(&prop, dev));
     {
         int per_cu = 16;                      // upper bound (sizes the per-workgroup tables); enqueue_batch picks 7, 8 or 16 per CU
@@ -2771,8 +2803,8 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         HC(hipMemset(t->d_image, 0, sizeof(float) * 3 * npix));
         t->own_image = true;
     }
-    // iterations per launch set: explicit option, or 8 (fewer for frames so large that 8 streams would not fit in
-    // ~16 GB).  With the first-bounce cache the iterations of a batch all start from the one cached bounce-0 stream
+    // iterations per launch set: explicit option, or the rule below (about 24 M paths per set, within a quarter of the device's
+    // memory).  With the first-bounce cache the iterations of a batch all start from the one cached bounce-0 stream
     int kmax = opt.batch;
     if (kmax <= 0) {
         // about 24 M paths per launch set, at least 12 iterations: 12 of a 1080p frame, up to 32 of a small frame or of one rank's tile
@@ -2781,12 +2813,21 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         // 64 GB of the 288.  Round 4: 12 instead of 5 at 3840x2160 (the rule was 16 GB with a guessed 400 B per path): every kernel of the
         // split bounce gets 2.4x the work per launch -- C5 1.23 -> 1.17 ms per iteration with round 3's kernels, and what the refilling
         // k_mesh needs: 1.4 M parked rays per launch instead of 0.6 M for the chip's 330 k lanes.
+        // Round 5: the 64 GB are a ceiling, not a constant -- a quarter of what the device (a CPX / NPS partition, a GPU shared by
+        // several ranks) has free or in total, whichever is less; and an allocation that still fails is retried with half the
+        // iterations per set (ptx_create below) before the caller is told.
         const long long owned = std::max(t->tm.owned, 1);
         long long want = ((24LL << 20) + owned / 2) / owned;
         want = std::min<long long>(32, std::max<long long>(12, want));
         const long long nl = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
-        kmax = (int)std::min<long long>(want, std::max<long long>(1, (64LL << 30) / (176LL * nl * owned)));
+        long long budget = 64LL << 30;
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total > 0) budget = std::min<long long>(budget, (long long)(std::min(mem_free, mem_total) / 4));
+        else (void)hipGetLastError();
+        if (const char *e = getenv("PTX_DEBUG_MEM_BUDGET_MB")) budget = std::max(1LL, atoll(e)) << 20;      // tests only
+        kmax = (int)std::min<long long>(want, std::max<long long>(1, budget / (176LL * nl * owned)));
     }
+    if (kmax_cap > 0 && kmax > kmax_cap) kmax = kmax_cap;      // (the retry after an allocation failed)
     if (kmax > 64) kmax = 64;
     // the per-tile prefix tables grow with bins x tiles x iterations in flight: keep them under 4 GiB by putting fewer
     // iterations into a launch set, then fewer launch sets in flight
@@ -2802,6 +2843,7 @@ int ptx_create(int ngeoms, const ptx_geom *geoms, int nmaterials, const ptx_mate
         }
     }
     t->kmax = kmax;
+    *kmax_used = kmax;
     // three launch sets in flight (one per stream) unless told otherwise: kernels of different sets overlap and
     // kernel tails are filled (C4, iterations per set x sets: 8 x 1 0.41, 8 x 2 0.30, 12 x 3 0.276, 12 x 4 0.31 ms per
     // iteration); also with one iteration per launch set, i.e. frames so large that only one fits the memory rule above
@@ -3203,6 +3245,20 @@ int ptx_get_stats(ptx_tracer *t, ptx_stats *out) {
     out->iterations = t->iterations;
     return PTX_OK;
 }
+
+int ptx_get_stats_sized(ptx_tracer *t, void *out, size_t out_bytes) {
+    if (!t || !out) return set_error(PTX_ERR_INVALID, "null argument");
+    ptx_stats s;
+    const int rc = ptx_get_stats(t, &s);
+    if (rc != PTX_OK) return rc;
+    memset(out, 0, out_bytes);
+    memcpy(out, &s, std::min(out_bytes, sizeof s));
+    return PTX_OK;
+}
+
+int ptx_abi_version(void) { return PTX_ABI_VERSION; }
+size_t ptx_sizeof_options(void) { return sizeof(ptx_options); }
+size_t ptx_sizeof_stats(void) { return sizeof(ptx_stats); }
 
 // ---- per-stage entry points -----------------------------------------------------------------------------------
 #define KAT_PROLOGUE                                                        \

@@ -20,6 +20,33 @@ import torch.distributed as dist
 TILE_ROWS = 8
 
 
+class RankFailed(RuntimeError):
+    """Raised by EVERY rank at the same point when some rank's local phase failed (see all_ok)."""
+
+
+def all_ok(ok, device=None):
+    """Every rank's verdict on a phase it ran LOCALLY, agreed on by all (all_reduce MIN): one rank's failure becomes every rank's
+    failure at the same point, so no rank goes on to a collective the failed one will never reach.  `device`: where the flag lives
+    (the rank's GPU for RCCL, None / cpu for gloo).  Itself a synchronisation point, like a barrier."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def agreed_phase(fn, device=None):
+    """Runs fn() on this rank under a try, then agrees with the other ranks on the outcome.  Returns (ok, message): ok is the same
+    on every rank; message names this rank's own exception, or says that another rank failed."""
+    err = None
+    try:
+        fn()
+    except Exception as e:          # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+        err = e
+    ok = all_ok(err is None, device)
+    if ok:
+        return True, None
+    return False, ("rank %d: %s" % (dist.get_rank(), str(err)[:260])) if err is not None else "another rank failed"
+
+
 def owned_rows(height, tile_rows, rank, world):
     """Rows y with (y // tile_rows) % world == rank -- the same rule the kernels apply (pt_engine.hip owned_pixel)."""
     return [y for y in range(height) if (y // tile_rows) % world == rank]

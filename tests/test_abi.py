@@ -29,7 +29,11 @@ def test_struct_layouts_match_the_reference_records(product):
     from mygpuraytracer_amd import api
     assert ctypes.sizeof(api.Material) == 44            # struct Material, sceneStructs.h:71-81
     assert ctypes.sizeof(api.Camera) == 84              # struct Camera ([probe] SURVEY 8)
-    assert ctypes.sizeof(api.Options) == 64
+    assert ctypes.sizeof(api.Options) == 68             # 17 int32 (round 5: + arith)
+    # the library says which revision of the structs it was compiled with, and the module checks it at load (api.load_library)
+    lib = product.load_library()
+    assert lib.ptx_abi_version() == api.ABI_VERSION == 5
+    assert lib.ptx_sizeof_options() == ctypes.sizeof(api.Options) and lib.ptx_sizeof_stats() == ctypes.sizeof(api.Stats)
 
 
 def test_no_cpu_fallback(product):
@@ -210,13 +214,14 @@ def test_headers_are_plain_c_and_link(product, tmp_path):
                    'int main(void) {\n    ptx_options opt; ptx_orbit orb; ptx_stats st; (void)orb; (void)st;\n'
                    '    ptx_default_options(&opt);\n    int in[5] = {1, 0, 2, 0, 3}, out[5];\n'
                    '    int n = sc_cpu_compact_without_scan(5, out, in);\n'
-                   '    printf("%d %d %d %d\\n", (int)sizeof(ptx_options), opt.antialiasing, opt.cache_first_bounce, n);\n    return 0;\n}\n')
+                   '    if (ptx_abi_version() != PTX_ABI_VERSION || ptx_sizeof_options() != sizeof opt || ptx_sizeof_stats() != sizeof st) return 2;\n'
+                   '    printf("%d %d %d %d %d\\n", (int)sizeof(ptx_options), opt.antialiasing, opt.cache_first_bounce, n, opt.arith);\n    return 0;\n}\n')
     exe = tmp_path / "abi"
     libdir = os.path.dirname(product.LIB_PATH)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), "-L", libdir, "-lmi355x_pathtracer", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([str(exe)], text=True).split()
-    assert out == ["64", "1", "1", "3"]
+    assert out == ["68", "1", "1", "3", "0"]
 
 
 def test_veneer_null_pbo_is_not_ambiguous(product, tmp_path):

@@ -218,3 +218,57 @@ def test_gather_of_owned_rows_equals_the_reduce(world, W, H, rows):
     assert all(got[r][0] is None for r in range(1, world))
     want = sum(got[r][2] for r in range(world))
     assert np.array_equal(got[0][0], got[0][1]) and np.array_equal(got[0][0], want)
+
+
+def _worker_agree(rank, world, port, q, failing_rank):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mygpuraytracer_amd import multigpu
+    log = []
+
+    def phase(name, fails):
+        def fn():
+            if fails and rank == failing_rank:
+                raise RuntimeError("%s broke here" % name)
+        ok, msg = multigpu.agreed_phase(fn)
+        log.append((name, ok, msg))
+        return ok
+
+    # the shape of bench.py's N-rank C5 leg: local phases chained by `and`, a collective only behind an agreed success, and a
+    # collective AFTER the leg that every rank must still reach whether or not the leg ran
+    if phase("assets", False) and phase("create", True) and phase("warm", False):
+        dist.barrier()
+        log.append(("collective", True, None))
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)                       # the roofline leg's stand-in: hangs if a rank left the protocol early
+    q.put((rank, log, int(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [0, 1])
+def test_a_rank_local_failure_is_every_ranks_failure(failing_rank):
+    """multigpu.agreed_phase (bench.py's N-rank legs): one rank raising inside a local phase makes EVERY rank skip the collectives
+    behind it and meet again at the next common point -- nobody waits in a barrier for a rank that has moved on."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_agree, args=(r, world, port, q, failing_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, log, total = q.get(timeout=120)
+        got[rank] = (log, total)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        log, total = got[rank]
+        assert total == 3                                                   # both ranks reached the common collective
+        assert [(n, ok) for n, ok, _ in log] == [("assets", True), ("create", False)]      # same verdicts everywhere, nothing behind the failure ran
+        msg = log[1][2]
+        assert ("rank %d: create broke here" % failing_rank) == msg if rank == failing_rank else msg == "another rank failed"

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B timing of prebuilt library variants (.ab/lib*.so) on one GPU box: bash tools/ab_bench.sh A B C ...
+# A/B timing of prebuilt library variants (abx/lib*.so) on one GPU box: bash tools/ab_bench.sh A B C ...
 # (the variant is loaded through PTX_AB_LIBRARY: the in-tree product library is never overwritten)
 for rep in $(seq 1 ${AB_REPS:-2}); do
 for v in "$@"; do
-  PTX_AB_LIBRARY=$PWD/.ab/lib$v.so python bench.py --no-cpu-baseline ${AB_BENCH_ARGS:-} > gpurun_out/ab_$v.log 2>&1
+  PTX_DEV=1 PTX_AB_LIBRARY=$PWD/abx/lib$v.so python bench.py --no-cpu-baseline ${AB_BENCH_ARGS:-} > gpurun_out/ab_$v.log 2>&1
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab_$v.log").read().strip().splitlines()[-1])

@@ -1,10 +1,10 @@
 #!/bin/bash
-# per-kernel durations (rocprofv3 --kernel-trace --stats) of the C5-shaped run for .ab/lib*.so variants: bash tools/ab_c5_profile.sh A B ...
+# per-kernel durations (rocprofv3 --kernel-trace --stats) of the C5-shaped run for abx/lib*.so variants: bash tools/ab_c5_profile.sh A B ...
 # (the variant is loaded through PTX_AB_LIBRARY, exported BEFORE rocprofv3 starts: no `env` hop between the profiler and python)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  export PTX_AB_LIBRARY=$R/.ab/lib$v.so
+  export PTX_DEV=1; export PTX_AB_LIBRARY=$R/abx/lib$v.so
   rm -rf $R/gpurun_out/c5prof_$v
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c5prof_$v -- python3 $R/tools/gpu_c5_profile.py > $R/gpurun_out/c5prof_$v.log 2>&1
   echo "== $v"; tail -1 $R/gpurun_out/c5prof_$v.log
