@@ -3,7 +3,9 @@
 // print-and-exit error policy (checkCUDAError, src/pathtrace.cu:42-60); the C ABI underneath returns codes.
 #include "pathtrace_api.h"
 
+#include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,13 +45,13 @@ Scene::Scene(const std::string &filename, const std::string &base_dir) : impl_(n
 Scene::~Scene() { ptx_scene_free(impl_); }
 
 void Scene::applyRunCudaCamera() {
-    *ptx_scene_camera(impl_) = state.camera;
+    *ptx_scene_camera(impl_) = *state.camera.c_abi();
     ptx_scene_apply_runcuda_camera(impl_);
     state.camera = *ptx_scene_camera(impl_);
 }
 
 bool Scene::runOrbitScript(const std::string &script) {
-    *ptx_scene_camera(impl_) = state.camera;
+    *ptx_scene_camera(impl_) = *state.camera.c_abi();
     ptx_orbit o;
     ptx_orbit_init(impl_, &o);
     ptx_orbit_apply(impl_, &o);
@@ -104,7 +106,56 @@ std::vector<int> &pathtraceDevices() {
     return devices;
 }
 
+// ---- PerformanceTimer, src/timer.h:17-100 ---------------------------------------------------------------------------------
+// (events are created on first use: the instance behind timer() is a function-local static that may be constructed before the
+// process has picked a device)
+PerformanceTimer::PerformanceTimer() {}
+PerformanceTimer::~PerformanceTimer() {
+    if (event_start) (void)hipEventDestroy((hipEvent_t)event_start);
+    if (event_end) (void)hipEventDestroy((hipEvent_t)event_end);
+}
+
+void PerformanceTimer::startCpuTimer() {
+    if (cpu_timer_started) throw std::runtime_error("CPU timer already started");
+    cpu_timer_started = true;
+    time_start_cpu_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now().time_since_epoch()).count();
+}
+
+void PerformanceTimer::endCpuTimer() {
+    const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now().time_since_epoch()).count();
+    if (!cpu_timer_started) throw std::runtime_error("CPU timer not started");
+    prev_elapsed_time_cpu_milliseconds = (float)((double)(now - time_start_cpu_ns) * 1e-6);
+    cpu_timer_started = false;
+}
+
+// The reference records on the null stream, which every one of ITS launches runs on.  Here the work runs on the tracer's own
+// (non-blocking) stream, so that is where the events go while a tracer exists: the interval then covers the pathtrace() calls
+// between start and end, as it does in the reference.
+static hipStream_t timer_stream() { return g_tracer ? (hipStream_t)ptx_stream(g_tracer) : (hipStream_t) nullptr; }
+
+void PerformanceTimer::startGpuTimer() {
+    if (gpu_timer_started) throw std::runtime_error("GPU timer already started");
+    gpu_timer_started = true;
+    if (!event_start) { hipEvent_t a = nullptr, b = nullptr; (void)hipEventCreate(&a); (void)hipEventCreate(&b); event_start = a; event_end = b; }
+    if (event_start) (void)hipEventRecord((hipEvent_t)event_start, timer_stream());
+}
+
+void PerformanceTimer::endGpuTimer() {
+    if (event_end) { (void)hipEventRecord((hipEvent_t)event_end, timer_stream()); (void)hipEventSynchronize((hipEvent_t)event_end); }
+    if (!gpu_timer_started) throw std::runtime_error("GPU timer not started");
+    float ms = 0.f;
+    if (event_start && event_end && hipEventElapsedTime(&ms, (hipEvent_t)event_start, (hipEvent_t)event_end) != hipSuccess) { ms = 0.f; (void)hipGetLastError(); }
+    prev_elapsed_time_gpu_milliseconds = ms;
+    gpu_timer_started = false;
+    gpu_interval_is_callers = true;
+}
+
+// pathtrace() ran: the module's timer answers with ITS bounce loop again, as after the reference's own start/endGpuTimer pair
+// inside pathtrace (src/pathtrace.cu:489, 545)
+void mi355x_timer_note_pathtrace(PerformanceTimer &t) { t.gpu_interval_is_callers = false; }
+
 float PerformanceTimer::getGpuElapsedTimeForPreviousOperation() {
+    if (gpu_interval_is_callers || this != &timer()) return prev_elapsed_time_gpu_milliseconds;
     if (!g_tracer) return 0.f;
     if (!g_multi) return (float)ptx_last_loop_ms(g_tracer);
     double ms = 0.0;                 // several devices work side by side: the slowest one's bounce loop
@@ -118,7 +169,7 @@ void pathtraceInit(Scene *scene) {
     const std::vector<int> &devs = pathtraceDevices();
     if (devs.size() > 1) {
         // the C ABI's multi-device layer takes the loaded scene: hand it the caller's camera and depth first
-        *ptx_scene_camera(scene->handle()) = scene->state.camera;
+        *ptx_scene_camera(scene->handle()) = *scene->state.camera.c_abi();
         ptx_scene_set_trace_depth(scene->handle(), scene->state.traceDepth);
         check(ptx_multi_create(scene->handle(), &pathtraceOptions(), devs.data(), (int)devs.size(), 0, &g_multi), "pathtraceInit");
         g_tracer = ptx_multi_tracer(g_multi, 0);
@@ -127,7 +178,7 @@ void pathtraceInit(Scene *scene) {
         ptx_options o = pathtraceOptions();
         if (devs.size() == 1) o.device = devs[0];
         check(ptx_create((int)scene->geoms.size(), scene->geoms.data(), (int)scene->materials.size(), scene->materials.data(),
-                         &scene->state.camera, scene->state.traceDepth, &o, nullptr, nullptr, &g_tracer),
+                         scene->state.camera.c_abi(), scene->state.traceDepth, &o, nullptr, nullptr, &g_tracer),
               "pathtraceInit");
         check(ptx_set_render_ahead(g_tracer, pathtraceRenderAhead() ? 1 : 0), "pathtraceInit");
     }
@@ -150,10 +201,11 @@ void pathtraceFree() {          // safe before init and idempotent, as main.cpp:
 void mi355x::pathtrace_raw(void *pbo, int frame, int iter) {
     (void)frame;                 // unused by the reference as well
     if (!g_tracer || !hst_scene) { fprintf(stderr, "pathtrace called before pathtraceInit\n"); exit(EXIT_FAILURE); }
+    mi355x_timer_note_pathtrace(timer());
     // the reference re-reads camera and traceDepth on every call (src/pathtrace.cu:434-436)
     const bool apps = pathtraceOptions().apps_variant != 0;
     if (g_multi) {               // several devices: every device its tile, then the row blocks into device 0's frame
-        check(ptx_multi_set_camera(g_multi, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
+        check(ptx_multi_set_camera(g_multi, hst_scene->state.camera.c_abi(), hst_scene->state.traceDepth), "pathtrace camera");
         check(ptx_multi_iterate(g_multi, iter), "pathtrace");
         check(ptx_multi_read_image(g_multi, &hst_scene->state.image[0].x), "image readback");      // assemble + :555-556
         if (!apps) check(ptx_write_pbo_device(g_tracer, iter, pbo), "sendImageToPBO");             // from the assembled frame
@@ -166,7 +218,7 @@ void mi355x::pathtrace_raw(void *pbo, int frame, int iter) {
         check(ptx_synchronize(g_tracer), "pathtrace");
         return;
     }
-    check(ptx_set_camera(g_tracer, &hst_scene->state.camera, hst_scene->state.traceDepth), "pathtrace camera");
+    check(ptx_set_camera(g_tracer, hst_scene->state.camera.c_abi(), hst_scene->state.traceDepth), "pathtrace camera");
     check(ptx_iterate(g_tracer, iter), "pathtrace");
     // apps/src builds with AI_DENOISE: no preview from here (sendToGPU shows the denoised frame), the albedo AOV comes back
     // with the image (apps/src/pathtrace.cu:658-669)

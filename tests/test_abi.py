@@ -253,3 +253,126 @@ def test_veneer_null_pbo_is_not_ambiguous(product, tmp_path):
         assert subprocess.call([str(exe)]) == 0          # (no tracer exists: pathtraceHandle() is NULL; nothing touches a GPU)
     for prog in ("tests/veneer_check.cpp", "tools/gpu_dropin_loop_cpp.cpp"):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, prog)])
+
+
+REF_MAIN = "/root/reference/src/main.cpp"
+REF_GLM = "/root/reference/external/include"
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_MAIN) and os.path.isdir(REF_GLM)), reason="needs the reference's main.cpp and vendored glm (dev container only)")
+def test_veneer_compiles_main_cpp_camera_block(tmp_path):
+    """The data members of Scene / RenderState / Camera that the reference's caller touches compile against the veneer AS WRITTEN: the
+    camera set-up of main() (src/main.cpp:50-70), runCuda()'s recompute (:105-123), the recentering key (:166-168), the middle-drag pan
+    (:195-206) and saveImage()'s pixel read (:89-90) are read from the reference's file at test time (text, never stored here), wrapped
+    in functions over main.cpp's own globals (:15-28), and compiled with the reference's vendored glm on the include path -- then RUN
+    against a stub of the struct (no library, no GPU): the camera block must compute what glm computes on plain glm members."""
+    import subprocess
+    lines = open(REF_MAIN).read().splitlines()
+    blk = lambda a, b: "\n".join(lines[a - 1:b])
+    src = tmp_path / "main_camera.cpp"
+    src.write_text('''#include <cmath>
+#include <cstdio>
+#include <glm/glm.hpp>
+#include "pathtrace_api.h"
+#define PI 3.14159265358979323846f
+static bool camchanged = true;
+float zoom, theta, phi;
+glm::vec3 cameraPosition;
+glm::vec3 ogLookAt;
+RenderState *renderState;
+static RenderState theState;
+int iteration;
+int width;
+int height;
+static double lastX = 3.0, lastY = 5.0;
+struct SceneStub { RenderState &state; } sceneStub{theState}, *scene = &sceneStub;
+void camera_setup() {
+%s
+}
+void runCuda_camera() {
+%s
+}
+void recenter() {
+%s
+}
+void middle_drag(double xpos, double ypos) {
+%s
+}
+glm::vec3 save_pixel(int index, float samples) {
+%s
+    return glm::vec3(pix) / samples;
+}
+int main() {
+    Camera &c = theState.camera;
+    c.resolution = mi355x::ivec2(800, 600);
+    c.position = glm::vec3(0.f, 5.f, 10.5f); c.lookAt = glm::vec3(0.f, 5.f, 0.f); c.view = glm::vec3(0.f, 0.f, -1.f); c.up = glm::vec3(0.f, 1.f, 0.f);
+    theState.image.assign(4, mi355x::vec3(1.f, 2.f, 3.f));
+    camera_setup();
+    runCuda_camera();
+    middle_drag(4.0, 7.0);
+    runCuda_camera();
+    // the same on plain glm members
+    glm::vec3 view(0.f, 0.f, -1.f), lookAt(0.f, 5.f, 0.f), position(0.f, 5.f, 10.5f);
+    float phi2 = glm::acos(glm::dot(glm::normalize(glm::vec3(view.x, 0.f, view.z)), glm::vec3(0, 0, -1)));
+    float theta2 = glm::acos(glm::dot(glm::normalize(glm::vec3(0.f, view.y, view.z)), glm::vec3(0, 1, 0)));
+    float zoom2 = glm::length(position - lookAt);
+    auto recompute = [&](glm::vec3 &v, glm::vec3 &u2, glm::vec3 &r, glm::vec3 &pos) {
+        glm::vec3 cp(zoom2 * sin(phi2) * sin(theta2), zoom2 * cos(theta2), zoom2 * cos(phi2) * sin(theta2));
+        v = -glm::normalize(cp); r = glm::cross(v, glm::vec3(0, 1, 0)); u2 = glm::cross(r, v); cp += lookAt; pos = cp;
+    };
+    glm::vec3 v, u2, r, pos;
+    recompute(v, u2, r, pos);
+    glm::vec3 fw = v; fw.y = 0.f; fw = glm::normalize(fw);
+    glm::vec3 rt = r; rt.y = 0.f; rt = glm::normalize(rt);
+    lookAt -= (float)(4.0 - 3.0) * rt * 0.01f;
+    lookAt += (float)(7.0 - 5.0) * fw * 0.01f;
+    recompute(v, u2, r, pos);
+    auto same = [](const mi355x::vec3 &a, const glm::vec3 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+    const bool ok = same(c.view, v) && same(c.up, u2) && same(c.right, r) && same(c.position, pos) && same(c.lookAt, lookAt) &&
+                    width == 800 && height == 600 && phi == phi2 && theta == theta2 && zoom == zoom2;
+    recenter();
+    const glm::vec3 px = save_pixel(2, 2.f);
+    const ptx_camera *abi = c.c_abi();
+    const bool ok2 = same(c.lookAt, glm::vec3(0.f, 5.f, 0.f)) && px.x == 0.5f && px.z == 1.5f && abi->resolution[0] == 800 && abi->view[2] == c.view.z &&
+                     abi->position[1] == c.position.y;
+    printf("%%d %%d\\n", ok ? 1 : 0, ok2 ? 1 : 0);
+    return ok && ok2 ? 0 : 1;
+}
+''' % (blk(50, 70), blk(105, 123), blk(166, 168), blk(195, 206), blk(89, 89)))
+    exe = tmp_path / "main_camera"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unused-variable", "-I", REF_GLM, "-I", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"),
+                           "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)], text=True).split() == ["1", "1"]
+
+
+def test_veneer_performance_timer_is_the_whole_class(product, tmp_path):
+    """csrc/pathtrace_api.h: PerformanceTimer has the reference's interface (src/timer.h:17-100) -- start/endCpuTimer measure real
+    time, the misuse exceptions are the reference's, it cannot be copied -- on the CPU side; the GPU side runs in the GPU tier."""
+    import subprocess
+    src = tmp_path / "timer.cpp"
+    src.write_text('''#include <chrono>
+#include <cstdio>
+#include <stdexcept>
+#include <thread>
+#include <type_traits>
+#include "pathtrace_api.h"
+int main() {
+    static_assert(!std::is_copy_constructible<PerformanceTimer>::value && !std::is_move_assignable<PerformanceTimer>::value, "uncopyable, unmovable");
+    PerformanceTimer t;
+    int caught = 0;
+    try { t.endCpuTimer(); } catch (const std::runtime_error &) { caught++; }
+    t.startCpuTimer();
+    try { t.startCpuTimer(); } catch (const std::runtime_error &) { caught++; }
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));
+    t.endCpuTimer();
+    const float ms = t.getCpuElapsedTimeForPreviousOperation();
+    try { t.endGpuTimer(); } catch (const std::runtime_error &) { caught++; }
+    printf("%d %d %d\\n", caught, ms >= 29.f && ms < 2000.f ? 1 : 0, timer().getGpuElapsedTimeForPreviousOperation() == 0.f ? 1 : 0);
+    return 0;
+}
+''')
+    exe = tmp_path / "timer"
+    libdir = os.path.dirname(product.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "mygpuraytracer_amd", "csrc"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmi355x_pathtracer", "-Wl,-rpath," + libdir])
+    assert subprocess.check_output([str(exe)], text=True).split() == ["3", "1", "1"]

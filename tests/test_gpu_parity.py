@@ -1166,6 +1166,12 @@ def test_cpp_veneer_like_main_cpp(gpu_product, tmp_path, apps):
     scene = os.path.join(ROOT, "scenes", "cornellObj.txt")
     out = subprocess.check_output([str(exe), scene, str(W), str(H), str(D), str(N), str(tmp_path / "v")] + (["apps"] if apps else []), text=True)
     assert float(out.split("time: ")[1].split()[0]) > 0.0
+    # src/timer.h:17-100 in full: the caller's own PerformanceTimer around one pathtrace() call -- both misuse exceptions thrown, a GPU
+    # and a CPU interval > 0 (events on the tracer's stream: with render-ahead the call's own stream work is the gather, the preview and
+    # the read-back, the batch traced ahead runs beside it) -- and timer() still answering with pathtrace's bounce loop (> 0)
+    tm = out.split("timers: ")[1].split()
+    caught, mine_gpu, mine_cpu, module = int(tm[1]), float(tm[3]), float(tm[5]), float(tm[7])
+    assert caught == 2 and mine_gpu > 0.0 and mine_cpu > 0.0 and module > 0.0
     rd = lambda ext, dt: np.frombuffer(open(str(tmp_path / "v") + ext, "rb").read(), dt)
     s = pt.Scene(scene, res=(W, H), depth=D)
     s.apply_runcuda_camera()
