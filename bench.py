@@ -244,6 +244,50 @@ def c5_per_iteration(pt, dev_index, iters=72):
     return dt / iters * 1e3, rays / iters, mix
 
 
+def arith_valu_counts():
+    """SQ_INSTS_VALU per k_bounce launch at each arithmetic level, from the committed counter passes (profiles/sq_latest.json = level 0,
+    profiles/sq_arith1.json / sq_arith2.json = `bench.py --arith N` under the same passes); None where a profile is missing."""
+    out = {}
+    for lv, f in ((0, "sq_latest.json"), (1, "sq_arith1.json"), (2, "sq_arith2.json")):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+            out[str(lv)] = dict(SQ_INSTS_VALU=(d.get("k_bounce") or {}).get("SQ_INSTS_VALU"), rays_per_launch=(d.get("_units_per_launch") or {}).get("k_bounce"), source="profiles/" + f)
+        except Exception:
+            out[str(lv)] = None
+    return out
+
+
+def arith_levels(pt, scene, dev_index, steps, warmup, lanes):
+    """The timed workload once more at the opt-in arithmetic levels (ptx_options.arith 1 = CONTRACTED: the same kernels as a second code
+    object with fused multiply-adds, the arithmetic the reference's real nvcc build has; 2 = FAST: + hardware reciprocal / square root /
+    sine).  Same steps, same bracketing, outside the timed region; `value` itself is always the exact level.  Results at these levels
+    agree with the exact one within the stated statistical tolerance (tests/test_gpu_arith.py), not bit for bit."""
+    out = {}
+    for lv, name in ((1, "contracted"), (2, "fast")):
+        with pt.Tracer(scene, device=dev_index, lanes=lanes, arith=lv) as T:
+            T.render(1, warmup)
+            T.synchronize()
+            t_warm, extra = time.perf_counter(), 0
+            while time.perf_counter() - t_warm < 0.15:
+                T.render(10_000_000 + extra, 36)
+                T.synchronize()
+                extra += 36
+            r0 = T.stats()["rays_total"]
+            t0 = time.perf_counter()
+            T.render(warmup + 1, steps)
+            T.synchronize()
+            dt = time.perf_counter() - t0
+            rays = T.stats()["rays_total"] - r0
+            r1 = T.stats()["rays_total"]
+            t0 = time.perf_counter()
+            T.render(20_000_000, 200)
+            T.synchronize()
+            lt = time.perf_counter() - t0
+            out[name] = dict(arith=lv, value=rays / dt / 1e6, unit="Mrays/s", steps=steps, ms_per_step=dt / steps * 1e3,
+                             long_run=dict(steps=200, ms_per_step=lt / 200 * 1e3, value=(T.stats()["rays_total"] - r1) / lt / 1e6), fenced=T.stats()["fenced"])
+    return out
+
+
 def stream_compaction_device(torch, pt, device):
     """the scan / compaction library on arrays already in HBM (sc_scan_device, sc_compact_device): achieved
     rate on algorithmic bytes (scan 4 B read + 4 B written per element; compaction 4 B read + 4 B per survivor) next to a
@@ -289,6 +333,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip dropin_per_call_ms and c5_ms_per_iteration (profiling runs)")
+    ap.add_argument("--arith", type=int, default=0, choices=[0, 1, 2],
+                    help="arithmetic level of the timed tracer (ptx_options.arith): 0 = exact, the default and the only level `value` is ever quoted "
+                         "at by the driver's command; 1 / 2 are for profiling the contracted / fast code objects (the line then says so in config.arith)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks: the frame is then reduced through host memory)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "iterations"],
@@ -367,7 +414,7 @@ def main():
     W, H = RES
     image = multigpu.frame_buffer(W, H, world, device)      # W*H*3 floats (+ padding rows when tiled, for the strided-view gather)
     torch.cuda.current_stream(device).synchronize()      # the tracer uses a stream of its own: the fill must have landed first
-    kw = dict(device=dev_index, lanes=args.lanes)
+    kw = dict(device=dev_index, lanes=args.lanes, arith=args.arith)
     by_iter = world > 1 and args.shard == "iterations"
     if world > 1 and not by_iter:
         kw.update(tile_rows=multigpu.TILE_ROWS, tile_rank=rank, tile_world=world)
@@ -571,7 +618,7 @@ def main():
     # HBM bytes and instruction counts per launch come from PMC counters, which need rocprofv3: they are NOT measured in this run but
     # taken from the committed profile of the same kernels (tools/profile_round.sh, tools/pmc_sq.sh -> profiles/), scaled from that
     # profile's rays per launch to this run's, and labelled as such.
-    traffic = traffic_source = None
+    traffic = traffic_source = tjd = None
     tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tj):
         try:
@@ -585,6 +632,21 @@ def main():
                     "scaled by rays per launch %.3g / %.3g" % (units, ref_units) if ref_units else "per launch of that profile, unscaled"))
         except Exception:
             traffic = None
+    # The WALL-level HBM figure (round 5): `frac` / `physical_frac` describe k_bounce alone, one launch set at a time, while `value` is
+    # wall time with three launch sets overlapped.  Counter bytes of ALL kernels of a launch set (the committed FETCH_SIZE / WRITE_SIZE
+    # profile: depth - 1 launches of k_bounce, the camera bounce, the gather; per launch of `_iterations_per_launch` iterations) per
+    # iteration, over this run's wall time per step, over the 8 TB/s peak.
+    physical_wall = None
+    try:
+        if tjd and all(k in tjd for k in ("k_bounce", "k_bounce<first>", "k_gather")) and world == 1:
+            ipl = float(tjd.get("_iterations_per_launch", 12))
+            set_bytes = (DEPTH - 1) * tjd["k_bounce"] + tjd["k_bounce<first>"] + tjd["k_gather"]
+            physical_wall = dict(bytes_per_step=set_bytes / ipl, TBps=set_bytes / ipl / (dt / args.steps) / 1e12,
+                                 frac=set_bytes / ipl / (dt / args.steps) / HBM_PEAK,
+                                 source="profiles/traffic_latest.json: (%d x k_bounce + k_bounce<first> + k_gather) counter bytes per launch of %d iterations, "
+                                        "/ this run's ms_per_step / 8 TB/s" % (DEPTH - 1, int(ipl)))
+    except Exception:
+        physical_wall = None
     valu_issue = None
     sj = os.path.join(ROOT, "profiles", "sq_latest.json")
     if os.path.exists(sj):
@@ -636,12 +698,13 @@ def main():
                            "of 32-64 B by what the next bounce can need, record_bytes); rounds 1-2 put the "
                            "contract's 196 B there, which now lives under contract_196B_frac -- BENCH_r02's frac compares with contract_196B_frac, not with frac",
                     measured_in_this_run=["achieved", "frac", "avg_launch_us", "launches", "units_per_launch", "kernels_ms_per_step", "contract_*", "loop_ms_per_step"],
-                    from_committed_profiles=["traffic", "traffic_over_algorithmic", "physical_frac", "valu_issue", "bound"], profiles=profiles_stale,
+                    from_committed_profiles=["traffic", "traffic_over_algorithmic", "physical_frac", "physical_frac_wall (bytes; the time is this run's)", "valu_issue", "bound"], profiles=profiles_stale,
                     bound="valu" if valu_issue and valu_issue["frac"] > achieved / HBM_PEAK else "hbm", kernel=dominant,
                     achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
                     algorithmic_bytes_per_unit=own_bytes, record_bytes=dict(mean=rec_bytes, with_direction=f_dir, with_normal=f_nrm), traffic=traffic, traffic_source=traffic_source,
                     traffic_over_algorithmic=(traffic / (own_bytes * units)) if traffic and own_bytes else None,
                     physical_frac=(traffic / avg_s / HBM_PEAK) if traffic and avg_s > 0 else None,
+                    physical_frac_wall=physical_wall["frac"] if physical_wall else None, physical_wall=physical_wall,
                     valu_issue=valu_issue,
                     contract_196B_frac=contract / HBM_PEAK,            # 196 B/ray of the reference's AoS records / launch time / 8 TB/s
                     contract_436B_loop_ratio=loop_contract / (HBM_PEAK * world),     # a RATIO (may exceed 1): the reference layout's loop bytes
@@ -655,7 +718,7 @@ def main():
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
                data="synthetic",
                primary_rays_per_s=RES[0] * RES[1] * args.steps / dt,      # px * spp / s of the whole job (beside Mrays/s)
-               config=dict(workload=WORKLOAD, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
+               config=dict(workload=WORKLOAD, arith=args.arith, rays_per_step=rays / args.steps, rays_per_bounce=rpb, clock_warmup_steps=clock_warmup_steps,
                            rccl_ranks=(dist.get_world_size() if dist_on else 1), backend=(args.backend if dist_on else None),
                            exchange=(None if not dist_on else "reduce" if by_iter else args.exchange),
                            timed_region_ms=dt * 1e3, slowest_rank_render_ms=t_render_max * 1e3,
@@ -690,6 +753,18 @@ def main():
         except Exception as e:
             out["dropin_per_call_ms"] = None
             out["dropin_per_call"] = dict(error=str(e)[:200])
+        try:
+            al = arith_levels(pt, scene, dev_index, args.steps, args.warmup, args.lanes)
+            out["value_contracted"] = al["contracted"]["value"]
+            out["value_fast"] = al["fast"]["value"]
+            out["arith_levels"] = dict(al, exact=dict(arith=0, value=out["value"], ms_per_step=out["ms_per_step"]),
+                                       what="the timed workload at ptx_options.arith 1 (fused multiply-adds: the arithmetic of the reference's real build) and 2 "
+                                            "(+ hardware rcp / rsq / sqrt / sin): same kernels as further code objects, results within the stated statistical "
+                                            "tolerance of the exact level (tests/test_gpu_arith.py); `value` is ALWAYS the exact level",
+                                       valu_instructions_per_k_bounce_launch=arith_valu_counts())
+        except Exception as e:
+            out["value_contracted"] = None
+            out["arith_levels"] = dict(error=str(e)[:200])
         try:
             c5_ms, c5_rays, c5_mix = c5_per_iteration(pt, dev_index)
             out["c5_ms_per_iteration"] = c5_ms

@@ -17,6 +17,22 @@
 #define PT_DEV __device__ __forceinline__
 #define PT_HD __host__ __device__ __forceinline__      // also compiled for the host (BVH checks on the CPU, pt_bvh.h)
 
+// ---- arithmetic level of this translation unit (ptx_options.arith, include/mi355x_pathtracer.h) ---------------------------------
+// 0  EXACT: everything this header's first comment says; the product's default and the only level any parity claim is made for.
+// 1  CONTRACTED: the same source compiled with -ffp-contract=fast (a*b+c becomes one fused multiply-add wherever the expression tree
+//    allows, as nvcc's default --fmad=true does to the reference's kernels); division and square root stay IEEE (nvcc's defaults
+//    --prec-div / --prec-sqrt too), sin / cos are an fp32 routine of about one ulp (as CUDA's sinf / cosf) instead of the correctly
+//    rounded binary64 one.
+// 2  FAST: level 1 + the hardware's approximate reciprocal / square root / reciprocal square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32:
+//    one ulp each, quotients a*rcp(b) about 2.5 ulp; -fno-hip-fp32-correctly-rounded-divide-sqrt) and its sine / cosine / exp2 / log2
+//    instructions.
+// Levels 1 and 2 are separate code objects (csrc/pt_arith.hip includes pt_engine.hip with PT_ARITH set and `ptd` renamed, so that no
+// inline function of theirs can ever be the copy the exact translation unit links) and promise a STATISTICAL tolerance against
+// level 0 (tests/test_gpu_parity.py::test_contracted_arithmetic_*), never bits.
+#ifndef PT_ARITH
+#define PT_ARITH 0
+#endif
+
 namespace ptd {
 
 struct vec3 { float x, y, z; };
@@ -45,7 +61,12 @@ PT_HD vec3 cross(vec3 x, vec3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - 
 #ifndef PT_FAST_EXACT
 #define PT_FAST_EXACT 1
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && PT_FAST_EXACT
+#if defined(__HIP_DEVICE_COMPILE__) && PT_ARITH >= 2
+// FAST: the hardware's seeds as they are (one ulp; no range handling: v_rsq / v_rcp of 0 give inf, as 1 / sqrt(0) does)
+__device__ __forceinline__ float pt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float pt_rsqrt_glm(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float pt_rcp_pos(float a) { return __builtin_amdgcn_rcpf(a); }
+#elif defined(__HIP_DEVICE_COMPILE__) && PT_FAST_EXACT
 // 2^-96 <= x < +inf as ONE unsigned compare on the bits (negative, zero, subnormal, tiny, inf and NaN fail it)
 __device__ __forceinline__ bool pt_in_core_range(float x) { return __float_as_uint(x) - 0x0f800000u < 0x70000000u; }
 __device__ __forceinline__ float pt_sqrt_core(float x) {
@@ -143,6 +164,44 @@ PT_DEV void sincos_own(float xf, float *s, float *c) {
     const double cd = __hiloint2double(__double2hiint(c0) ^ (int)(((uint32_t)(k + 1) & 2u) << 30), __double2loint(c0));
     *s = (float)sd;
     *c = (float)cd;
+}
+
+#if PT_ARITH >= 1
+// sin and cos in binary32 for |x| <= 1e5 (the path tracer passes |x| <= 2 pi): nearest multiple of pi/2 removed in two fused steps
+// (Cody-Waite, pi/2 = hi + lo with hi's low bits zero), then the classic minimax polynomials on [-pi/4, pi/4] (Cephes sinf / cosf):
+// about one ulp, the class of CUDA's sinf / cosf.  FAST takes the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions).
+PT_DEV void sincos_f32(float x, float *s, float *c) {
+#if PT_ARITH >= 2
+    const float rev = x * 0.15915494309189535f;
+    *s = __builtin_amdgcn_sinf(rev);
+    *c = __builtin_amdgcn_cosf(rev);
+#else
+    const float kf = __builtin_rintf(x * 0.6366197723675814f);
+    const int k = (int)kf;
+    float r = __builtin_fmaf(-kf, 1.5703125f, x);                     // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+    r = __builtin_fmaf(-kf, 4.837512969970703125e-4f, r);
+    r = __builtin_fmaf(-kf, 7.54978995489188e-8f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    const bool swap = (k & 1) != 0;
+    const float s0 = swap ? cr : sr, c0 = swap ? sr : cr;
+    *s = __uint_as_float(__float_as_uint(s0) ^ (((uint32_t)k & 2u) << 30));
+    *c = __uint_as_float(__float_as_uint(c0) ^ (((uint32_t)(k + 1) & 2u) << 30));
+#endif
+}
+#endif
+// what the samplers call: the correctly rounded binary64 routine (EXACT) or the binary32 one
+PT_DEV void sincos_pt(float x, float *s, float *c) {
+#if PT_ARITH >= 1
+    sincos_f32(x, s, c);
+#else
+    sincos_own(x, s, c);
+#endif
 }
 
 PT_DEV double pow5_own(double x) {
@@ -1346,7 +1405,7 @@ PT_DEV vec3 randomDirectionInHemisphere(vec3 normal, Rng &rng) {
     vec3 perp1 = normalize(cross(normal, notNormal));
     vec3 perp2 = normalize(cross(normal, perp1));
     float sn, cs;
-    sincos_own(around, &sn, &cs);
+    sincos_pt(around, &sn, &cs);
     vec3 a = scale(normal, up);
     vec3 b = scale(perp1, cs * over);
     vec3 c = scale(perp2, sn * over);
@@ -1474,7 +1533,7 @@ PT_DEV void concentricSampleDisk(float px, float py, float &ox, float &oy) {
         theta = 1.570796f - 0.785398f * (ux / uy);
     }
     float sn, cs;
-    sincos_own(theta, &sn, &cs);
+    sincos_pt(theta, &sn, &cs);
     ox = r * cs;
     oy = r * sn;
 }

@@ -1770,7 +1770,7 @@ __global__ void k_kat_libm(int n, const float *x, float *s, float *c, const doub
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float sn, cs;
-    sincos_own(x[i], &sn, &cs);
+    sincos_pt(x[i], &sn, &cs);          // (the routine the samplers call: sincos_own at the exact level)
     s[i] = sn; c[i] = cs;
     p5[i] = pow5_own(pw[i]);
     pout[i] = powf_own(pxy[2 * i], pxy[2 * i + 1]);
@@ -1798,7 +1798,84 @@ __global__ void k_kat_fast_exact(unsigned long long *mism) {
     if (m2) atomicAdd(&mism[2], m2);
 }
 
+// ---- the arithmetic-bearing kernels of THIS translation unit as a table of launchers ---------------------------------------------
+// The file is compiled once per arithmetic level (pt_device.h: PT_ARITH; levels 1 and 2 through csrc/pt_arith.hip, each a code object
+// of its own).  Only the level-0 translation unit holds the host side; it launches through one of these tables, its own or one it
+// gets from ptx_arith_kernels_<level>().  Plain types in the signatures (the parameter blocks travel as const void *): the structs are
+// the same source in every translation unit but, formally, types of different anonymous namespaces.
+struct KernelSet {
+    int arith;
+    void (*bounce)(int first, int mode, int fast, dim3 grid, size_t lds, hipStream_t st, const void *bounce_params);
+    void (*mesh)(int first, dim3 grid, size_t lds, hipStream_t st, const void *bounce_params, int bvh_stack);
+    void (*finish)(int first, dim3 grid, hipStream_t st, const void *bounce_params);
+    void (*kat_geom)(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out);
+    void (*kat_intersect)(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out);
+    void (*kat_tile)(int split, dim3 grid, size_t lds, hipStream_t st, const void *sc, const void *scg, int n, const void *paths, void *out, int uses_uv);
+    void (*kat_shade)(dim3 grid, hipStream_t st, const void *scene, int iter, int n, const int32_t *idx, const void *isects, void *paths);
+    void (*kat_generate)(dim3 grid, hipStream_t st, const void *cam, int iter, int traceDepth, int aa, int dof, void *paths);
+    void (*kat_libm)(dim3 grid, hipStream_t st, int n, const float *x, float *s, float *c, const double *pw, double *p5, const float *pxy, float *pout);
+};
+
+template <bool FIRST, int MODE>
+void launch_bounce_variant(bool fast, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
+    if (fast) hipLaunchKernelGGL((k_bounce<FIRST, MODE, true>), grid, dim3(TILE), lds - (MODE == 0 ? sizeof(int32_t) * (17 - REC_ROWS_FAST0) * TILE : 0), stream, bp);
+    else hipLaunchKernelGGL((k_bounce<FIRST, MODE, false>), grid, dim3(TILE), lds, stream, bp);
+}
+void ks_bounce(int first, int mode, int fast, dim3 grid, size_t lds, hipStream_t stream, const void *params) {
+    const BounceParams &bp = *static_cast<const BounceParams *>(params);
+    if (first) {
+        if (mode == 0) launch_bounce_variant<true, 0>(fast != 0, grid, lds, stream, bp);
+        else if (mode == 1) launch_bounce_variant<true, 1>(fast != 0, grid, lds, stream, bp);
+        else launch_bounce_variant<true, 2>(fast != 0, grid, lds, stream, bp);
+    } else {
+        if (mode == 0) launch_bounce_variant<false, 0>(fast != 0, grid, lds, stream, bp);
+        else if (mode == 1) launch_bounce_variant<false, 1>(fast != 0, grid, lds, stream, bp);
+        else launch_bounce_variant<false, 2>(fast != 0, grid, lds, stream, bp);
+    }
+}
+void ks_mesh(int first, dim3 grid, size_t lds, hipStream_t stream, const void *params, int bvh_stack) {
+    const BounceParams &bp = *static_cast<const BounceParams *>(params);
+    if (first) hipLaunchKernelGGL(k_mesh<true>, grid, dim3(256), lds, stream, bp, bvh_stack);
+    else hipLaunchKernelGGL(k_mesh<false>, grid, dim3(256), lds, stream, bp, bvh_stack);
+}
+void ks_finish(int first, dim3 grid, hipStream_t stream, const void *params) {
+    const BounceParams &bp = *static_cast<const BounceParams *>(params);
+    if (first) hipLaunchKernelGGL(k_finish<true>, grid, dim3(256), 0, stream, bp);
+    else hipLaunchKernelGGL(k_finish<false>, grid, dim3(256), 0, stream, bp);
+}
+void ks_kat_geom(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out) {
+    hipLaunchKernelGGL(k_kat_geom, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), gi, n, rays, out);
+}
+void ks_kat_intersect(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out) {
+    hipLaunchKernelGGL(k_kat_intersect, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), n, static_cast<const HostPath *>(paths), static_cast<HostIsect *>(out));
+}
+void ks_kat_tile(int split, dim3 grid, size_t lds, hipStream_t st, const void *sc, const void *scg, int n, const void *paths, void *out, int uses_uv) {
+    const DScene &a = *static_cast<const DScene *>(sc), &b = *static_cast<const DScene *>(scg);
+    if (split) hipLaunchKernelGGL(k_kat_tile<true>, grid, dim3(TILE), lds, st, a, b, n, static_cast<const HostPath *>(paths), static_cast<HostIsect *>(out), uses_uv);
+    else hipLaunchKernelGGL(k_kat_tile<false>, grid, dim3(TILE), lds, st, a, b, n, static_cast<const HostPath *>(paths), static_cast<HostIsect *>(out), uses_uv);
+}
+void ks_kat_shade(dim3 grid, hipStream_t st, const void *scene, int iter, int n, const int32_t *idx, const void *isects, void *paths) {
+    hipLaunchKernelGGL(k_kat_shade, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), iter, n, idx, static_cast<const HostIsect *>(isects), static_cast<HostPath *>(paths));
+}
+void ks_kat_generate(dim3 grid, hipStream_t st, const void *cam, int iter, int traceDepth, int aa, int dof, void *paths) {
+    hipLaunchKernelGGL(k_kat_generate, grid, dim3(256), 0, st, *static_cast<const DCamera *>(cam), iter, traceDepth, aa, dof, static_cast<HostPath *>(paths));
+}
+void ks_kat_libm(dim3 grid, hipStream_t st, int n, const float *x, float *s, float *c, const double *pw, double *p5, const float *pxy, float *pout) {
+    hipLaunchKernelGGL(k_kat_libm, grid, dim3(256), 0, st, n, x, s, c, pw, p5, pxy, pout);
+}
+const KernelSet g_kernels_here = {PT_ARITH, ks_bounce, ks_mesh, ks_finish, ks_kat_geom, ks_kat_intersect, ks_kat_tile, ks_kat_shade, ks_kat_generate, ks_kat_libm};
+
 }  // namespace
+
+#if PT_ARITH != 0
+// this translation unit is one of the extra code objects: all it exports is its table
+#define PT_ARITH_EXPORT_(n) ptx_arith_kernels_##n
+#define PT_ARITH_EXPORT(n) PT_ARITH_EXPORT_(n)
+extern "C" const void *PT_ARITH_EXPORT(PT_ARITH)(void) { return &g_kernels_here; }
+#else
+// the other arithmetic levels' tables (weak: a library linked without csrc/pt_arith.hip's objects still loads, and refuses arith != 0)
+extern "C" const void *ptx_arith_kernels_1(void) __attribute__((weak));
+extern "C" const void *ptx_arith_kernels_2(void) __attribute__((weak));
 
 // ---------------------------------------------------------------------------------------------------------------
 struct ptx_tracer {
@@ -1904,6 +1981,7 @@ struct ptx_tracer {
         return s;
     }
     bool cache_active() const { return opt.cache_first_bounce && !opt.antialiasing && !opt.depth_of_field; }
+    const KernelSet *ks = &g_kernels_here;               // the code object the arithmetic-bearing kernels are launched from (ptx_options.arith)
 };
 
 namespace {
@@ -2183,11 +2261,6 @@ const char *fast_violation(const ptx_tracer *t, int mode, bool first, bool needs
     return nullptr;
 }
 
-template <bool FIRST, int MODE>
-void launch_bounce_variant(bool fast, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
-    if (fast) hipLaunchKernelGGL((k_bounce<FIRST, MODE, true>), grid, dim3(TILE), lds - (MODE == 0 ? sizeof(int32_t) * (17 - REC_ROWS_FAST0) * TILE : 0), stream, bp);
-    else hipLaunchKernelGGL((k_bounce<FIRST, MODE, false>), grid, dim3(TILE), lds, stream, bp);
-}
 // the one launch site of k_bounce: picks the variant by the predicate above
 int launch_bounce(const ptx_tracer *t, bool first, int mode, bool needs_albedo, dim3 grid, size_t lds, hipStream_t stream, const BounceParams &bp) {
     const char *why = fast_violation(t, mode, first, needs_albedo, bp);
@@ -2196,15 +2269,7 @@ int launch_bounce(const ptx_tracer *t, bool first, int mode, bool needs_albedo, 
         if (why) return set_error(PTX_ERR_INVALID, std::string("specialised k_bounce requested outside its preconditions: ") + why);
         fast = true;
     }
-    if (first) {
-        if (mode == 0) launch_bounce_variant<true, 0>(fast, grid, lds, stream, bp);
-        else if (mode == 1) launch_bounce_variant<true, 1>(fast, grid, lds, stream, bp);
-        else launch_bounce_variant<true, 2>(fast, grid, lds, stream, bp);
-    } else {
-        if (mode == 0) launch_bounce_variant<false, 0>(fast, grid, lds, stream, bp);
-        else if (mode == 1) launch_bounce_variant<false, 1>(fast, grid, lds, stream, bp);
-        else launch_bounce_variant<false, 2>(fast, grid, lds, stream, bp);
-    }
+    t->ks->bounce(first ? 1 : 0, mode, fast ? 1 : 0, grid, lds, stream, &bp);
     return PTX_OK;
 }
 
@@ -2381,10 +2446,8 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // sets stops.  With three, k_mesh alone is 4 % slower and C5's wall time 2 % shorter (1.066 -> 1.045 ms per iteration; 4: 1.054,
             // 2: 1.059; nine runs each on one box); a wave also draws from 460 rays instead of 270.
             const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WG_PER_CU) / K);
-            if (first) KT(2, { hipLaunchKernelGGL(k_mesh<true>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
-                               hipLaunchKernelGGL(k_finish<true>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
-            else KT(2, { hipLaunchKernelGGL(k_mesh<false>, dim3(mesh_gx, K), dim3(256), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, bp, t->bvh_stack);
-                         hipLaunchKernelGGL(k_finish<false>, dim3(std::max(1, grid / K), K), dim3(256), 0, stream, bp); });
+            KT(2, { t->ks->mesh(first ? 1 : 0, dim3(mesh_gx, K), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, &bp, t->bvh_stack);
+                    t->ks->finish(first ? 1 : 0, dim3(std::max(1, grid / K), K), stream, &bp); });
             const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
             KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx_b, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
@@ -2564,7 +2627,17 @@ static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, cons
     if (dev >= ndev) return set_error(PTX_ERR_INVALID, "device ordinal out of range");
     HIPCHECK(hipSetDevice(dev));
 
+    const KernelSet *ks = &g_kernels_here;
+    if (opt.arith != PTX_ARITH_EXACT) {
+        const void *tab = opt.arith == 1 ? (ptx_arith_kernels_1 ? ptx_arith_kernels_1() : nullptr)
+                        : opt.arith == 2 ? (ptx_arith_kernels_2 ? ptx_arith_kernels_2() : nullptr) : nullptr;
+        if (opt.arith < 0 || opt.arith > 2) return set_error(PTX_ERR_INVALID, "ptx_options.arith: 0 (exact), 1 (contracted) or 2 (fast)");
+        if (!tab) return set_error(PTX_ERR_UNSUPPORTED, "this library was built without the code object of arithmetic level " + std::to_string(opt.arith));
+        ks = static_cast<const KernelSet *>(tab);
+        if (ks->arith != opt.arith) return set_error(PTX_ERR_HIP, "arithmetic code object mismatch");
+    }
     ptx_tracer *t = new ptx_tracer;
+    t->ks = ks;
     t->device = dev; t->opt = opt; t->traceDepth = trace_depth; t->ngeoms = ngeoms; t->nmats = nmaterials;
     camera_to_device(*camera, t->cam);
     const int W = t->cam.resx, H = t->cam.resy;
@@ -3274,7 +3347,7 @@ int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float 
     HIPCHECK(hipMalloc(&d_in.p, sizeof(float) * 6 * (size_t)n));
     HIPCHECK(hipMalloc(&d_out.p, sizeof(float) * 10 * (size_t)n));
     HIPCHECK(hipMemcpy(d_in, rays6, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_geom, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), geom, n, d_in, d_out);
+    { const DScene sc = t->scene(); t->ks->kat_geom(dim3((n + 255) / 256), t->stream, &sc, geom, n, d_in, d_out); }
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(out10, d_out, sizeof(float) * 10 * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
@@ -3287,7 +3360,7 @@ int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, voi
     HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
     HIPCHECK(hipMalloc(&d_i.p, sizeof(HostIsect) * (size_t)n));
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_intersect, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), n, d_p, d_i);
+    { const DScene sc = t->scene(); t->ks->kat_intersect(dim3((n + 255) / 256), t->stream, &sc, n, d_p.p, d_i.p); }
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
@@ -3318,8 +3391,7 @@ int ptx_kat_tile_intersect(ptx_tracer *t, int n, const void *paths44, void *isec
                              std::to_string(t->bvh_stack) + " stack entries per lane), the device offers " + std::to_string(lim));
     }
     const dim3 grid((unsigned)std::min(1024, (n + TILE - 1) / TILE));
-    if (split) hipLaunchKernelGGL(k_kat_tile<true>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
-    else hipLaunchKernelGGL(k_kat_tile<false>, grid, dim3(TILE), lds, t->stream, sc, scg, n, d_p, d_i, t->uses_uv);
+    t->ks->kat_tile(split ? 1 : 0, grid, lds, t->stream, &sc, &scg, n, d_p.p, d_i.p, t->uses_uv);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(isects32, d_i, sizeof(HostIsect) * (size_t)n, hipMemcpyDeviceToHost));
@@ -3336,7 +3408,7 @@ int ptx_kat_shade(ptx_tracer *t, int iter, int n, const int32_t *idx, const void
     HIPCHECK(hipMemcpy(d_p, paths44, sizeof(HostPath) * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_i, isects32, sizeof(HostIsect) * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_x, idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_shade, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->scene(), iter, n, d_x, d_i, d_p);
+    { const DScene sc = t->scene(); t->ks->kat_shade(dim3((n + 255) / 256), t->stream, &sc, iter, n, d_x.p, d_i.p, d_p.p); }
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
@@ -3347,8 +3419,7 @@ int ptx_kat_generate(ptx_tracer *t, int iter, void *paths44) {
     int n = t->cam.resx * t->cam.resy;
     DevBuf<HostPath> d_p;
     HIPCHECK(hipMalloc(&d_p.p, sizeof(HostPath) * (size_t)n));
-    hipLaunchKernelGGL(k_kat_generate, dim3((n + 255) / 256), dim3(256), 0, t->stream, t->cam, iter, t->traceDepth,
-                       t->opt.antialiasing, t->opt.depth_of_field, d_p);
+    t->ks->kat_generate(dim3((n + 255) / 256), t->stream, &t->cam, iter, t->traceDepth, t->opt.antialiasing, t->opt.depth_of_field, d_p.p);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(paths44, d_p, sizeof(HostPath) * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
@@ -3365,7 +3436,7 @@ int ptx_kat_libm(ptx_tracer *t, int n, const float *x, float *sin_out, float *co
     HIPCHECK(hipMemcpy(dx, x, 4 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dpw, pw_in, 8 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dxy, powf_xy, 8 * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kat_libm, dim3((n + 255) / 256), dim3(256), 0, t->stream, n, dx, ds, dc, dpw, dp5, dxy, dpo);
+    t->ks->kat_libm(dim3((n + 255) / 256), t->stream, n, dx.p, ds.p, dc.p, dpw.p, dp5.p, dxy.p, dpo.p);
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(sin_out, ds, 4 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(cos_out, dc, 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -3614,3 +3685,5 @@ int ptx_debug_read_stream(ptx_tracer *t, int *n_out, int32_t *pixel_index, int32
 }
 
 }  // extern "C"
+
+#endif  // PT_ARITH == 0: the host side

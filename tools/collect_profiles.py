@@ -55,6 +55,7 @@ def main(tag, d_stats, d_fetch, d_write):
     res["_how"] = how_of(d_fetch) + ("; bytes per launch = mean(FETCH_SIZE)*1024*2 + mean(WRITE_SIZE)*1024; the factor 2 is the gfx950 "
                    "FETCH_SIZE correction (checked in round 1 on the then k_move: ~77 MB of dword-per-lane reads expected, counter 40.5 MB; WRITE_SIZE "
                    "checked on torch's 24.9 MB fill = 24300 KiB).")
+    res["_iterations_per_launch"] = 12       # the default batch at 1080p, which the profiled command runs with (bench.py: physical_frac_wall)
     res["_source_sha16"] = source_sha16()      # of the kernel sources this was collected with (bench.py warns when they have changed since)
     json.dump(res, open(os.path.join(out, "traffic_%s.json" % tag), "w"), indent=1)
     if "c5" not in tag:                                # what bench.py reads

@@ -50,7 +50,10 @@ def main(tag):
     out["_source_sha16"] = source_sha16()      # of the kernel sources this was collected with (bench.py warns when they have changed since)
     p = os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)
     json.dump(out, open(p, "w"), indent=1, sort_keys=True)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "sq_latest.json"), "w"), indent=1, sort_keys=True)      # what bench.py reads
+    # what bench.py reads: sq_latest.json (the exact level), or -- `python tools/collect_sq.py TAG --as sq_arith1.json` -- the file of
+    # another arithmetic level's passes (PMC_EXTRA_ARGS="--arith 1" bash tools/pmc_sq.sh TAG)
+    latest = sys.argv[sys.argv.index("--as") + 1] if "--as" in sys.argv else "sq_latest.json"
+    json.dump(out, open(os.path.join(ROOT, "profiles", latest), "w"), indent=1, sort_keys=True)
     for k in ("k_bounce", "k_bounce<first>", "k_move"):
         if k in out:
             print(k, json.dumps(out[k]["_derived"]), {c: round(v) for c, v in out[k].items() if not c.startswith("_")})

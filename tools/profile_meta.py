@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("pt_engine.hip", "pt_device.h", "pt_bvh.h", "Makefile")
+KERNEL_SOURCES = ("pt_engine.hip", "pt_device.h", "pt_bvh.h", "pt_arith.hip", "Makefile")
 
 
 def source_sha16():
