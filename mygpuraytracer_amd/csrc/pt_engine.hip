@@ -624,6 +624,10 @@ __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, i
 #ifndef PT_QCAP
 #define PT_QCAP (4 * TILE)
 #endif
+#ifndef PT_DIRECT_STORE
+#define PT_DIRECT_STORE 1      // round 5: a tile's stored paths go from registers to their stage slots (no transposition through LDS), every wave
+                               // derives the tile's in-tile offsets itself, keys are written for stored slots only: three barriers per tile instead of six
+#endif
 #ifndef PT_RANK_SLICED
 #define PT_RANK_SLICED 1       // later bounces, <= 16 bins: the in-wave ranking bit-sliced instead of one pass per bin that occurs
 #endif
@@ -692,6 +696,19 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     const int iter = p.iter + seg * p.iter_stride;
     const PathSoA in_k = soa_offset(p.in, p.seg_in * seg), stage_k = soa_offset(p.stage, p.seg_stage * seg);
     int32_t *counts_all = p.counts_all + p.seg_counts * seg, *counts_scat = p.counts_scat + p.seg_counts * seg;
+    // stored paths per tile (a third block behind the two prefix tables): the tail reads only that many keys of a tile -- slots beyond hold
+    // no record and, since round 5, no "no record" key either (4 B written and 4 B read per ended path of a 256-path tile saved)
+    int32_t *tile_np = counts_all + 2 * (size_t)nb * p.maxTiles;
+    // The tile epilogue without LDS (PT_DIRECT_STORE; up to 64 bins: lane b of EVERY wave owns bin b).  Until round 5 the stored paths of a
+    // tile were written into an LDS record buffer at their slots, and read back in slot order for dense stores, behind wave 0's scan of
+    // the per-bin counts: three barriers (counts ready, records in LDS, buffer free again) after the ranking's own, every one of them a
+    // wait for the slowest of four waves -- 18 % of k_bounce's wave cycles sat in "ranking" and 8 % in "sort + write" for ~230 vector
+    // instructions.  Now every wave sums the four waves' counts and scans them itself (the same ~20 instructions, nobody waits for wave
+    // 0), a lane fetches its bin's offset from lane `bin` (ds_bpermute) and stores its record's quads straight to slot offset + rank:
+    // lanes of one bin are consecutive slots, a wave's store is a handful of contiguous runs.  What is left per tile: the two barriers
+    // of the pair test and the ranking's one.  The histogram rows a wave zeroes are now its OWN, after the pair test's barriers (every
+    // wave has then left the previous tile): no other wave can still be reading them.
+    const bool direct = PT_DIRECT_STORE && MODE != 2 && (FAST || nb <= 64);      // (the specialised variants are only launched with <= 64 bins: fast_violation)
     int32_t *chunk_out = p.chunk + p.seg_chunk * seg;
     int32_t *super_all = p.super_all + p.seg_totals * seg, *super_scat = p.super_scat + p.seg_totals * seg;
     int32_t *totals_all = p.totals_all + p.seg_totals * seg, *totals_scat = p.totals_scat + p.seg_totals * seg;
@@ -880,7 +897,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         // ranking histogram (read after later barriers).  The ranking pass (MODE 2) has no intersection whose barriers would separate
         // this from the ballots' writes: it zeroes the histogram right after a tile's LAST read of it instead (below), and once before
         // its first tile -- three barriers per tile instead of five for a kernel that is a chain of barriers and little else.
-        if (MODE != 2) for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
+        if (MODE != 2 && !direct) for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
         ps.o = ps.d = ps.color = V3(0.f, 0.f, 0.f);
         unsigned long long key = KEY_NONE;
         int32_t k1 = 0;
@@ -960,7 +977,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             int mbin = 0;
             bool mpend = false;
             if (alive) classifyRay(hit, ps, pix, mbin, mpend);
-            st_u(stage.idx(), (uint32_t)i << 2, (int32_t)-1);
+            if (tid == 0) tile_np[tile] = 0;
             if (tid == 0) run_all[p.sort ? p.sc.nmats - 1 : 0] += min(TILE, n_in - tile * TILE);
             continue;
         }
@@ -970,7 +987,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             int mbin = 0;
             bool mpend = false;
             if (alive) classifyRay(hit, ps, pix, mbin, mpend);
-            st_u(stage.idx(), (uint32_t)i << 2, (int32_t)-1);
+            if (tid == 0) tile_np[tile] = 0;
             const int missbin = p.sort ? p.sc.nmats - 1 : 0, nalive = min(TILE, n_in - tile * TILE);
             for (int b = tid; b < nb; b += TILE) {
                 counts_all[(size_t)b * p.maxTiles + tile] = b == missbin ? nalive : 0;
@@ -1070,6 +1087,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         }
         STAMP(1);        // intersect
     classify:
+        // (direct epilogue: this wave's rows of the ranking histogram -- every path to here has passed a barrier of THIS tile, so no wave
+        // is still summing the previous tile's)
+        if (MODE != 2 && direct && lane < nb) { w_all[wave * nb + lane] = 0; w_scat[wave * nb + lane] = 0; }
         if (MODE != 2 && alive) classifyRay(hit, ps, pix, bin, pending);
         STAMP(2);        // classify + deposit
         // stable rank of this path inside its tile, per material bin: among all alive paths (-> RNG stream
@@ -1128,7 +1148,23 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         if (alive) {
             for (int w = 0; w < wave; w++) { r_all += w_all[w * nb + bin]; r_scat += w_scat[w * nb + bin]; }
         }
-        if (nb <= 64) {
+        int toff_bin = 0, npend_r = 0;       // direct epilogue: this path's bin's offset in the tile, the tile's stored paths
+        if (direct) {
+            int ln = lane;                   // (opaque, see below)
+            asm volatile("" : "+v"(ln));
+            int ca = 0, cs = 0;
+            if (ln < nb) for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + ln]; cs += w_scat[w * nb + ln]; }
+            if (wave == 0 && ln < nb) {      // the tile's place in the chunk: one wave's business, as before
+                counts_all[(size_t)ln * p.maxTiles + tile] = MODE == 1 ? ca : run_all[ln];
+                counts_scat[(size_t)ln * p.maxTiles + tile] = MODE == 1 ? cs : run_scat[ln];
+                run_all[ln] += ca;
+                run_scat[ln] += cs;
+            }
+            const int inc = waveInclusiveScan(cs, ln);
+            npend_r = __builtin_amdgcn_readlane(inc, 63);              // (lanes >= nb add 0)
+            toff_bin = __builtin_amdgcn_ds_bpermute((bin < 0 ? 0 : bin) << 2, inc - cs);
+            STAMP(14);
+        } else if (nb <= 64) {
             // wave 0: lane b owns bin b -- tile counts, running prefixes and the in-tile offsets by a wave scan
             if (wave == 0) {
                 // `ln` = lane, but opaque to the optimiser: otherwise the per-lane addresses below are loop invariants,
@@ -1176,7 +1212,44 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                                                                                // the barrier below is in front of the next tile's ballots)
             if (pending) keybuf[myslot] = stage_key(bin, r_all, r_scat);
             __syncthreads();
+            // (stored paths fill the slots from the bottom -- pass 1's records and k_finish's parked ones are not contiguous: keys for every slot)
             st_u(soa_fresh(stage_k).idx(), (uint32_t)i << 2, keybuf[tid]);
+            if (FIRST && tid == 0) tile_np[tile] = TILE;          // (the camera bounce's ranking pass reads the counts: tiles pass 1 finished have fewer keys)
+            continue;
+        }
+        if (direct) {
+            const PathSoA stage = soa_fresh(stage_k);
+            const bool partial = MODE == 1 && pass1_partial;         // (pass 2 writes such a tile's keys and its count)
+            if (partial && i < n_in) {
+                if (alive) k1 = K1_ALIVE | bin | (pending ? K1_PEND | ((toff_bin + r_scat) << 16) : 0);
+                st_u(stage.lsrc(), (uint32_t)i << 2, k1);
+            }
+            if (pending) {
+                const uint32_t g4 = (uint32_t)(tile * TILE + toff_bin + r_scat) << 2, g16 = g4 << 2;
+                const vec3 sp = add(ps.o, scale(ps.d, hit.t));      // the point shadeFakeMaterial will shade (:392)
+                const bool with_dir = !dir_some || ((p.dir_bins >> bin) & 1ull);
+                const bool coded_n = ntab_some && ((p.ntab_bins >> bin) & 1ull);
+                typedef float quad __attribute__((ext_vector_type(4)));
+                quad A, B;
+                A.x = sp.x; A.y = sp.y; A.z = sp.z; A.w = __int_as_float(coded_n ? (pix | (hit.ncode << 28)) : pix);
+                B.x = ps.color.x; B.y = ps.color.y; B.z = ps.color.z; B.w = __int_as_float(hit.mat | (hit.geom << 16));
+                st_u(reinterpret_cast<quad *>(stage.quadA()), g16, A);
+                st_u(reinterpret_cast<quad *>(stage.quadB()), g16, B);
+                if (with_dir) {
+                    quad D;
+                    D.x = ps.d.x; D.y = ps.d.y; D.z = ps.d.z; D.w = p.uses_uv ? hit.v : 0.f;
+                    st_u(reinterpret_cast<quad *>(stage.quadD()), g16, D);
+                }
+                if (!coded_n) {
+                    quad C;
+                    C.x = hit.n.x; C.y = hit.n.y; C.z = hit.n.z; C.w = p.uses_uv ? hit.u : 0.f;
+                    st_u(reinterpret_cast<quad *>(stage.quadC()), g16, C);
+                }
+                if (!partial) st_u(stage.idx(), g4, stage_key(bin, r_all, r_scat));
+            }
+            if (!partial && tid == 0) tile_np[tile] = npend_r;
+            STAMP(4);
+            if (MODE == 1 && *qcnt > QCAP - TILE) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: the tile's last atomic on it lies before the ranking's barrier)
             continue;
         }
         if (MODE == 1 && pass1_partial && i < n_in) {
@@ -1231,6 +1304,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             } else {
                 st_u(stage.idx(), gi4, (int32_t)-1);
             }
+            if (tid == 0) tile_np[tile] = npend;
         }
         __syncthreads();
         STAMP(4);        // sort through LDS + stage write
@@ -1278,10 +1352,22 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA stage = soa_fresh(stage_k);
         const int32_t *keys = stage.idx();
         constexpr int MOVE_U = 4;                                     // tiles per step: their keys are requested before the first is used
+        // (only the slots that hold a record are read: the tile's stored count, left by whoever finished the tile -- requested one step
+        // ahead, so that the keys stay ONE round trip per step; the ranking pass of a later bounce wrote a key for every slot itself)
+        constexpr bool NP_ALL = MODE == 2 && !FIRST;
+        int np_next[MOVE_U];
+#pragma unroll
+        for (int u = 0; u < MOVE_U; u++) np_next[u] = tile0 + u < tile1 ? (NP_ALL ? TILE : tile_np[tile0 + u]) : 0;
         for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
             int32_t key[MOVE_U];
+            int np_cur[MOVE_U];
 #pragma unroll
-            for (int u = 0; u < MOVE_U; u++) key[u] = tbase + u < tile1 ? ld_u(keys, (uint32_t)((tbase + u) * TILE + tid) << 2) : -1;
+            for (int u = 0; u < MOVE_U; u++) {
+                np_cur[u] = np_next[u];
+                np_next[u] = tbase + MOVE_U + u < tile1 ? (NP_ALL ? TILE : tile_np[tbase + MOVE_U + u]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < MOVE_U; u++) key[u] = tid < np_cur[u] ? ld_u(keys, (uint32_t)((tbase + u) * TILE + tid) << 2) : -1;
 #pragma unroll
             for (int u = 0; u < MOVE_U; u++) {
                 if (key[u] == -1) continue;
@@ -1899,7 +1985,7 @@ struct ptx_tracer {
     float *d_fbuf[3] = {nullptr, nullptr, nullptr};      // stream, stage, cache
     int32_t *d_ibuf[3] = {nullptr, nullptr, nullptr};
     PathSoA soa[3];                                      // 0, 1 = the two stages (bounce b writes soa[1 - (b & 1)], b + 1 reads it), 2 = first-bounce cache
-    int32_t *d_counts = nullptr;                         // [2][nbins][maxTiles]
+    int32_t *d_counts = nullptr;                         // per segment: [2][nbins][maxTiles] prefix tables + [maxTiles] stored paths per tile
     int32_t *d_chunk = nullptr;                          // [segments][2 (bounce parity)][3][nbins x grid_seg]: the run tables (BounceParams::chunk)
     int32_t *d_cache_chunk = nullptr;                    // [3][nbins x grid_seg]: the cached bounce 0's
     int32_t *d_cache_super = nullptr;                    // [2][nbins][nsuper]: the cached bounce 0's
@@ -2247,6 +2333,7 @@ int free_tracer(ptx_tracer *t) {
 const char *fast_violation(const ptx_tracer *t, int mode, bool first, bool needs_albedo, const BounceParams &bp) {
     if (!bp.part) return "no per-iteration radiance buffers (part == NULL): the variant stores, it never adds to the image";
     if (!bp.sort || bp.nbins != std::max(t->nmats, 1)) return "sort_by_material = 0: the per-bin tables hold one bin";
+    if (bp.nbins > 64) return "more than 64 material bins (lane b of a wave owns bin b in the variant's tile epilogue)";
     if (bp.emit_count) return "the cache-filling pass (emit_count != NULL) records bounce-0 light hits";
     if (needs_albedo) return "the launch set contains iteration 1 of the apps variant (albedo AOV)";
     if (!bp.sc.cull || !bp.sc.tri_lds) return "candidate masks or LDS scene tables are off";
@@ -2343,7 +2430,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     const int gx = gx_later;
     const int nsuper = (gx + 63) / 64;
     const size_t chunk_cap = (size_t)nb * t->grid_seg;                 // runs per table at most
-    const size_t seg_counts = 2 * (size_t)nb * t->maxTiles, seg_chunk = 2 * 3 * chunk_cap, seg_totals = t->seg_totals;
+    const size_t seg_counts = (2 * (size_t)nb + 1) * t->maxTiles, seg_chunk = 2 * 3 * chunk_cap, seg_totals = t->seg_totals;      // (two prefix tables + stored paths per tile)
     int32_t *counts_all = t->d_counts + seg0 * seg_counts, *counts_scat = counts_all + (size_t)nb * t->maxTiles;
     // run tables of bounce b: parity b & 1 of the segment's pair (bounce b + 1 reads them while it writes its own)
     auto chunks = [&](int bounce) { return t->d_chunk + seg0 * seg_chunk + (size_t)(bounce & 1) * 3 * chunk_cap; };
@@ -2906,7 +2993,7 @@ static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, cons
     // iterations into a launch set, then fewer launch sets in flight
     {
         const int want_lanes = opt.lanes >= 1 ? std::min(opt.lanes, MAX_LANES) : 3;
-        auto counts_bytes = [&](int k, int l) { return sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * (size_t)k * l; };
+        auto counts_bytes = [&](int k, int l) { return sizeof(int32_t) * (2 * (size_t)t->nbins + 1) * t->maxTiles * (size_t)k * l; };
         while (counts_bytes(kmax, want_lanes) > (4ULL << 30) && kmax > 1) kmax /= 2;
         if (counts_bytes(kmax, want_lanes) > (4ULL << 30)) opt.lanes = t->opt.lanes = 1;
         if (counts_bytes(kmax, 1) > (4ULL << 30) && opt.lanes == 1) {
@@ -2998,7 +3085,7 @@ static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, cons
         HC(hipMalloc(&t->d_albedo, sizeof(float) * 3 * npix));
         HC(hipMemset(t->d_albedo, 0, sizeof(float) * 3 * npix));
     }
-    HC(hipMalloc(&t->d_counts, sizeof(int32_t) * 2 * (size_t)t->nbins * t->maxTiles * nseg));
+    HC(hipMalloc(&t->d_counts, sizeof(int32_t) * (2 * (size_t)t->nbins + 1) * t->maxTiles * nseg));
     t->nsuper = (t->grid_seg + 63) / 64;
     HC(hipMalloc(&t->d_chunk, sizeof(int32_t) * 2 * 3 * (size_t)t->nbins * t->grid_seg * nseg));
     HC(hipMemset(t->d_chunk, 0, sizeof(int32_t) * 2 * 3 * (size_t)t->nbins * t->grid_seg * nseg));

@@ -18,6 +18,7 @@ def timed(T, first, count, reps=3):
 def main():
     ensure_standin_assets()
     levels = (0, 1, 2) if "--no-timing" not in sys.argv else ()
+    if "--levels" in sys.argv: levels = tuple(int(x) for x in sys.argv[sys.argv.index("--levels") + 1].split(","))
     s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(1920, 1080), depth=8); s.apply_runcuda_camera()
     for lv in levels:
         with pt.Tracer(s, arith=lv) as T:
