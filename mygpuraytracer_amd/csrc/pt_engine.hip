@@ -296,6 +296,7 @@ struct BounceParams {
     // not a fault, and is COUNTED here (ptx_stats.fenced, 0 in every test): a wrong pixel is never the only symptom.
     unsigned long long *fenced;
     uint32_t fence_slots;
+    uint32_t fence_slots_cap;              // maxTiles x TILE itself (fence_slots is that too, unless a test lowered it): where a segment's lit flags start
 };
 __device__ __forceinline__ void fence_report(const BounceParams &p) { atomicAdd(p.fenced, 1ull); }
 
@@ -321,10 +322,17 @@ __device__ __forceinline__ void st_rgb(float *base, uint32_t byteoff, float r, f
     *reinterpret_cast<RgbUnaligned *>(reinterpret_cast<char *>(base) + byteoff) = v;
 #endif
 }
-__device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, bool batched, int pix, vec3 c, int apps) {
+// Batched mode, round 5: only paths that end WITH radiance (a light hit, an emissive texel) write their 12 bytes, and set the pixel's byte
+// in the segment's "lit" flags, which lie behind the segment's radiance ([cap] floats x 3, then [cap] bytes; cleared per batch, 1 B per
+// pixel).  The many that end black -- misses, the last bounce: most path ends of a Cornell frame -- write nothing, and k_gather adds only
+// flagged slots: adding the +0 they used to store changes no sum (the image holds no -0: it starts at +0 and only grows), so the frames
+// are the same bits.  C4 moved 12 B per path end and 12 B per pixel and iteration in k_gather for those zeros: 11 % of its HBM bytes.
+__device__ __forceinline__ uint8_t *lit_flags(float *part, uint32_t cap) { return reinterpret_cast<uint8_t *>(part + 3 * (size_t)cap); }
+__device__ __forceinline__ void deposit(const TileMap &tm, float *image, float *part, bool batched, int pix, vec3 c, int apps, uint32_t cap) {
     if (apps) c = scale(c, 3.14159265358f);            // apps/src/pathtrace.cu:44,508: image += color * PI
     if (batched) {
         st_rgb(part, (uint32_t)pix * 12u, c.x, c.y, c.z);
+        st_u(lit_flags(part, cap), (uint32_t)pix, (uint8_t)1);
     } else {
         float *px = image + (size_t)slot_to_pixel(tm, pix) * 3;
         px[0] += c.x; px[1] += c.y; px[2] += c.z;
@@ -511,7 +519,7 @@ __device__ __forceinline__ void classifyPath(const BounceParams &p, int iter, fl
         if (m.emittance > 0.0f) {                           // src/pathtrace.cu:380-383
             lit = true;
             vec3 c = mul(color, scale(V3(m.color[0], m.color[1], m.color[2]), m.emittance));
-            deposit(p.tm, p.image, part, batched, pix, c, p.apps);
+            deposit(p.tm, p.image, part, batched, pix, c, p.apps, p.fence_slots_cap);
             if (FIRST && p.emit_count) {
                 const vec3 cd = p.apps ? scale(c, 3.14159265358f) : c;
                 int k = atomicAdd(p.emit_count, 1);
@@ -522,13 +530,9 @@ __device__ __forceinline__ void classifyPath(const BounceParams &p, int iter, fl
             pending = true;
         }
     }
-    // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image, but
-    // in batched mode the path's slot of the per-iteration buffer must still be written
-    if (batched && !pending && !lit) {
-        float z = 0.f;
-        asm volatile("" : "+v"(z));      // (a hoisted zero vector ends up spilled to scratch in this kernel)
-        st_rgb(part, (uint32_t)pix * 12u, z, z, z);
-    }
+    // a miss or a last-bounce hit ends the path with colour 0 (:388, :400): nothing to add to the image -- and, since round 5, nothing to
+    // store in batched mode either (the pixel's "lit" flag of this iteration stays clear: k_gather skips the slot)
+    (void)lit;
 }
 
 // inclusive prefix sum over the lanes of a wave, in the vector ALU's own lane network (DPP): four shifted adds inside the rows of 16
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 Rng rng; rng.seed(iter, sidx, 0);
                 bool ended = (FAST && MODE == 0) ? scatterRay<false>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng)
                                                  : scatterRay<true>(p.sc, ps, intersect, h, getMaterial(p.sc, h.mat), rng);
-                if (ended && rec_ok) deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps);      // emissive texel: remainingBounces 1 -> 0, colour goes to the image
+                if (ended && rec_ok) deposit(p.tm, p.image, part, batched, pix, ps.color, p.apps, p.fence_slots_cap);      // emissive texel: remainingBounces 1 -> 0, colour goes to the image
                 if (ended || !rec_ok) alive = false;
             }
         }
@@ -1629,7 +1633,7 @@ __global__ void k_capture(PathSoA stage, const int32_t *chunk, int chunk_cap, in
 // add != 0: image[pix] += rgb (one iteration at a time); add == 0: store into the per-iteration radiance buffer of each of
 // the nseg segments (batched mode; the buffers were cleared, so bounce-0 misses read as 0)
 __global__ void k_replay_emission(TileMap tm, const int32_t *count, const int32_t *pix, const float *rgb, float *dst, size_t seg_stride,
-                                  int nseg, int add) {
+                                  int nseg, int add, uint32_t cap) {
     int n = *count;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const float r = rgb[k * 3 + 0], g = rgb[k * 3 + 1], b = rgb[k * 3 + 2];
@@ -1640,6 +1644,7 @@ __global__ void k_replay_emission(TileMap tm, const int32_t *count, const int32_
             for (int sg = 0; sg < nseg; sg++) {
                 float *px = dst + seg_stride * sg + (size_t)pix[k] * 3;
                 px[0] = r; px[1] = g; px[2] = b;
+                lit_flags(dst + seg_stride * sg, cap)[pix[k]] = 1;
             }
         }
     }
@@ -1651,15 +1656,19 @@ __global__ void k_seed_totals(int32_t *dst, size_t seg_totals, int nseg, const i
 }
 
 // batched mode: image[pix] += part[0][pix]; += part[1][pix]; ... in iteration order, over the pixels this device owns
-__global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const float *part, float *image) {
+// (only the slots whose "lit" flag of that iteration is set hold anything: see deposit)
+__global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const float *part, float *image, uint32_t cap) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tm.owned; i += gridDim.x * blockDim.x) {
         int x, y;
         owned_pixel(tm, i, x, y);
         const size_t o = ((size_t)x + (size_t)y * resx) * 3;
+        bool any = false;
+        for (int s = 0; s < nseg; s++) any = any || reinterpret_cast<const uint8_t *>(part + seg_part * s + 3 * (size_t)cap)[i] != 0;
+        if (!any) continue;                              // (a pixel no iteration of the batch lit: its sum does not move)
         float r = image[o], g = image[o + 1], b = image[o + 2];
         for (int s = 0; s < nseg; s++) {
             const float *ps = part + seg_part * s + (size_t)i * 3;
-            r += ps[0]; g += ps[1]; b += ps[2];
+            if (reinterpret_cast<const uint8_t *>(part + seg_part * s + 3 * (size_t)cap)[i]) { r += ps[0]; g += ps[1]; b += ps[2]; }
         }
         image[o] = r; image[o + 1] = g; image[o + 2] = b;
     }
@@ -2438,6 +2447,10 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     auto supers = [&](int bounce, int which) { return t->d_super + seg0 * seg_totals + ((size_t)bounce * 2 + which) * nb * t->nsuper; };
     // per-bounce totals and group totals are accumulated with atomics: clear them once per batch
     HIPCHECK(hipMemsetAsync(t->d_totals + seg0 * seg_totals, 0, sizeof(int32_t) * seg_totals * (size_t)K, stream));
+    // ... and the batch's "lit" flags (behind each segment's radiance: cap bytes per segment, one strided memset)
+    if (K > 1 || t->lanes > 1)
+        HIPCHECK(hipMemset2DAsync(reinterpret_cast<char *>(t->d_part + seg0 * t->seg_part) + sizeof(float) * 3 * (size_t)t->cap, sizeof(float) * t->seg_part, 0,
+                                  (size_t)t->cap, (size_t)K, stream));
 
     // per-kernel timing brackets (only when switched on; costs two event records per launch)
     auto kt_begin = [&](int kind) -> int {
@@ -2471,13 +2484,13 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             // when primary rays are not jittered, so bounce 0 is skipped (intent of src/pathtrace.cu:492-499,514)
             hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(256), 0, stream, totals(0, 0), seg_totals, K, t->d_cache_totals, 2 * nb);
             if (batched) {
+                // (the cached bounce-0 misses need nothing: their flags were cleared with the batch's)
                 const size_t seg_part = t->seg_part;
-                HIPCHECK(hipMemsetAsync(t->d_part + seg0 * seg_part, 0, sizeof(float) * seg_part * (size_t)K, stream));
                 hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->tm, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
-                                   t->d_part + seg0 * seg_part, seg_part, K, 0);
+                                   t->d_part + seg0 * seg_part, seg_part, K, 0, (uint32_t)t->cap);
             } else {
                 hipLaunchKernelGGL(k_replay_emission, dim3(64), dim3(256), 0, stream, t->tm, t->d_emit_count, t->d_emit_pix, t->d_emit_rgb,
-                                   t->d_image, (size_t)0, 1, 1);
+                                   t->d_image, (size_t)0, 1, 1, (uint32_t)t->cap);
             }
             continue;
         }
@@ -2516,7 +2529,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         bp.part = batched ? t->d_part + seg0 * bp.seg_part : nullptr;
         bp.emit_count = (first && fill_cache) ? t->d_emit_count : nullptr;
         bp.emit_pix = t->d_emit_pix; bp.emit_rgb = t->d_emit_rgb;
-        bp.fenced = reinterpret_cast<unsigned long long *>(t->d_stats + 65); bp.fence_slots = t->fence_slots;
+        bp.fenced = reinterpret_cast<unsigned long long *>(t->d_stats + 65); bp.fence_slots = t->fence_slots; bp.fence_slots_cap = (uint32_t)t->cap;
         bp.tile_geoms = (first && t->tile_geoms_valid) ? t->d_tile_geoms : nullptr;
         if (t->split_mesh) {
             bp.keys = t->d_keys + seg0 * (size_t)t->cap; bp.seg_keys = (size_t)t->cap;
@@ -2568,7 +2581,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
     if (prev_lane >= 0 && prev_lane != lane) HIPCHECK(hipStreamWaitEvent(stream, t->ev_chain[prev_lane], 0));      // the previous batch's gather + stats
     if (batched)
         hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, stream, t->tm, t->cam.resx, K,
-                           t->seg_part, t->d_part + seg0 * t->seg_part, t->d_image);
+                           t->seg_part, t->d_part + seg0 * t->seg_part, t->d_image, (uint32_t)t->cap);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, t->d_totals + seg0 * seg_totals, nb, t->traceDepth, 2 * nb, use_cache ? 1 : 0, K,
                        seg_totals, t->d_stats, t->d_stats + 64, batch_dir_bins, batch_ntab_bins, t->d_stats + 66);
     if (t->lanes > 1) HIPCHECK(hipEventRecord(t->ev_chain[lane], stream));
@@ -2626,7 +2639,7 @@ int ahead_finish_segment(ptx_tracer *t, int lane, int seg) {
     const size_t sg = (size_t)lane * t->kmax + seg, seg_part = t->seg_part;
     HIPCHECK(hipStreamWaitEvent(t->stream, t->ev_ahead1[lane], 0));
     hipLaunchKernelGGL(k_gather, dim3(std::min(2048, (t->tm.owned + 255) / 256)), dim3(256), 0, t->stream, t->tm, t->cam.resx, 1,
-                       seg_part, t->d_part + sg * seg_part, t->d_image);
+                       seg_part, t->d_part + sg * seg_part, t->d_image, (uint32_t)t->cap);
     hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, t->stream, t->d_totals + sg * t->seg_totals, t->nbins, t->traceDepth, 2 * t->nbins,
                        a.use_cache ? 1 : 0, 1, t->seg_totals, t->d_stats, t->d_stats + 64, a.dir_bins, a.ntab_bins, t->d_stats + 66);
     HIPCHECK(hipGetLastError());
@@ -3045,7 +3058,8 @@ static int create_tracer(int ngeoms, const ptx_geom *geoms, int nmaterials, cons
         HC(hipMalloc(&t->d_ibuf[k], sizeof(int32_t) * SOA_INTS * stride));
         carve(t->soa[k], t->d_fbuf[k], t->d_ibuf[k], stride);
     }
-    t->seg_part = 3 * (size_t)t->cap;                 // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles
+    t->seg_part = 3 * (size_t)t->cap + (size_t)t->cap / 4;      // per-iteration radiance of the OWNED pixels (slot-indexed), whole tiles, then the
+                                                                // iteration's "lit" flags, a byte per slot (cap is a multiple of 256)
     if (nseg > 1) HC(hipMalloc(&t->d_part, sizeof(float) * t->seg_part * nseg));
     {   // split mesh search: worth it when some mesh is big enough for a BVH; needs the candidate masks (cull, <= 32 geoms: a
         // parked ray carries one bit per mesh whose box it reaches) and a queue entry per ray in the worst case
