@@ -632,6 +632,9 @@ __device__ __forceinline__ void windowLoad(int32_t *win, const int32_t *chunk, i
 #define PT_DIRECT_STORE 1      // round 5: a tile's stored paths go from registers to their stage slots (no transposition through LDS), every wave
                                // derives the tile's in-tile offsets itself, keys are written for stored slots only: three barriers per tile instead of six
 #endif
+#ifndef PT_RANK_ONE_BARRIER
+#define PT_RANK_ONE_BARRIER 0  // experiment (see RANK1 in k_bounce): the ranking pass of the split bounce with one barrier per tile
+#endif
 #ifndef PT_RANK_SLICED
 #define PT_RANK_SLICED 1       // later bounces, <= 16 bins: the in-wave ranking bit-sliced instead of one pass per bin that occurs
 #endif
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     const int nb = p.nbins;
     const int triWords = (MODE != 2 && p.sc.tri_lds) ? sceneLdsWords(p.sc) : 0;      // (pass 2 of the split bounce only ranks: no scene tables)
     int32_t *lds = pt_lds + triWords;
-    int32_t *w_all = lds, *w_scat = lds + WAVES * nb;
+    int32_t *w_all = lds, *w_scat = lds + WAVES * nb;              // (the ranking pass alternates between this histogram and a second one: below)
     int32_t *run_all = lds + 2 * WAVES * nb, *run_scat = run_all + nb;
     int32_t *tcs = run_scat + nb, *toff = tcs + nb;                 // stored-path count per bin of this tile, its prefix
     int32_t *tcnt = toff + nb + 1;                                  // tileIntersect's list counters [2][4], zero between uses
@@ -876,7 +879,19 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
     };
     int32_t *ccnt = qcnt + 2;                                   // MODE 1: candidates of the tile so far (LDS)
     int32_t k1_next = 0;                                        // MODE 2: the next tile's word, requested one tile ahead
-    if (MODE == 2) {                                            // (its histogram: zeroed here once, then after every tile's ranking)
+    // The ranking pass (MODE 2) with ONE barrier per tile (round 5; three until then: counts by wave 0, keys scattered to their slots through
+    // LDS).  What it owes the tail is a key per STORED path at the path's slot; the slot is in the word pass 1 / k_finish left, so the key
+    // is stored there directly.  Slots without a record need no "-1" any more: the tail reads a tile's keys only where records can lie --
+    // pass 1's at the bottom, the parked rays' at the top (tile_np: both counts) -- and k_finish marks the parked rays that ended.  The
+    // per-bin counts are bookkeeping of their owner thread (thread b owns bin b, every tile), nobody waits for them.  The histogram
+    // alternates between two buffers, each wave zeroing its OWN rows at the start of a tile: whoever still sums the previous tile's
+    // reads the other buffer, and the tile before that lies behind the previous tile's barrier.
+    // MEASURED AND NOT KEPT (PT_RANK_ONE_BARRIER 0; tools/runs/r5f.sh, one box, Lit = three barriers / Rank1 = this form): the pass
+    // alone 0.147 -> 0.140 ms per iteration of C5, the wall 0.893 -> 0.904.  The pass is not a chain of barriers after all -- at 4K it
+    // moves 0.45 GB per launch in 0.2 ms -- and keys scattered 4 B at a time cost the three launch sets more than its barriers did.
+    constexpr bool RANK1 = MODE == 2 && PT_RANK_ONE_BARRIER;
+    int rank_par = 0;
+    if (MODE == 2 && !RANK1) {                                  // (its histogram: zeroed here once, then after every tile's ranking)
         for (int k = tid; k < 2 * WAVES * nb; k += TILE) lds[k] = 0;
         __syncthreads();
     }
@@ -921,8 +936,13 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 run_all[b] += ca;
                 run_scat[b] += cs;
             }
-            __syncthreads();
+            if (!RANK1) __syncthreads();      // (thread b is bin b's owner in every tile: nobody else reads the running prefixes before the tail)
             continue;
+        }
+        if (RANK1) {                          // this tile's histogram buffer, this wave's rows of it
+            w_all = rank_par ? rec : lds; w_scat = w_all + WAVES * nb;
+            rank_par ^= 1;
+            for (int k = lane; k < nb; k += 64) { w_all[wave * nb + k] = 0; w_scat[wave * nb + k] = 0; }
         }
         int bin = -1;
         bool pending = false, pass1_partial = false;
@@ -1058,7 +1078,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                                      p.uses_uv != 0, hit);
                 goto classify;
             } else if (MODE == 2) {
-                rec[tid] = -1;                                    // this slot's key, until a stored path claims the slot (keybuf below;
+                if (!RANK1) rec[tid] = -1;                        // this slot's key, until a stored path claims the slot (keybuf below;
                                                                   // the barriers of the ranking lie between this and the claims)
             } else if (p.sc.cull) {
                 // The specialised kernel is compiled for PT_FAST_WAVES waves per SIMD, i.e. 72 registers.  The thread's own state
@@ -1105,7 +1125,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             // vector instructions per bin that occurs in the wave instead of 28.  (Visiting EVERY bin in turn instead -- no readlane,
             // no find-first -- is 13 per bin and loses: camera rays see two or three of the eight bins.)
             const int abin = alive ? bin : -1, pbin = pending ? bin : -1;
-            if (PT_RANK_SLICED && MODE != 2 && !FIRST && nb <= 16) {
+            if (PT_RANK_SLICED && (MODE != 2 || RANK1) && !FIRST && nb <= 16) {
                 // Up to 16 bins, later bounces (a wave of scattered rays sees four or five of the bins): bit-sliced.  Four ballots give the
                 // lanes whose bin has bit k set; a lane ANDs together, per bit of its OWN bin, that mask or its complement -- the lanes of
                 // its bin, as a 64-bit value of its own -- and ranks itself with v_mbcnt on it: ~30 vector instructions whatever the number
@@ -1151,6 +1171,19 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         STAMP(13);       // (ranking: wait at its first barrier)
         if (alive) {
             for (int w = 0; w < wave; w++) { r_all += w_all[w * nb + bin]; r_scat += w_scat[w * nb + bin]; }
+        }
+        if (RANK1) {
+            for (int b = tid; b < nb; b += TILE) {               // bin b's owner: the tile's place in the chunk
+                int ca = 0, cs = 0;
+                for (int w = 0; w < WAVES; w++) { ca += w_all[w * nb + b]; cs += w_scat[w * nb + b]; }
+                counts_all[(size_t)b * p.maxTiles + tile] = run_all[b];
+                counts_scat[(size_t)b * p.maxTiles + tile] = run_scat[b];
+                run_all[b] += ca;
+                run_scat[b] += cs;
+            }
+            if (pending) st_u(soa_fresh(stage_k).idx(), (uint32_t)(tile * TILE + myslot) << 2, stage_key(bin, r_all, r_scat));
+            STAMP(3);
+            continue;
         }
         int toff_bin = 0, npend_r = 0;       // direct epilogue: this path's bin's offset in the tile, the tile's stored paths
         if (direct) {
@@ -1218,7 +1251,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
             // (stored paths fill the slots from the bottom -- pass 1's records and k_finish's parked ones are not contiguous: keys for every slot)
             st_u(soa_fresh(stage_k).idx(), (uint32_t)i << 2, keybuf[tid]);
-            if (FIRST && tid == 0) tile_np[tile] = TILE;          // (the camera bounce's ranking pass reads the counts: tiles pass 1 finished have fewer keys)
+            if (tid == 0) tile_np[tile] = TILE;                   // (this form writes a key for every slot)
             continue;
         }
         if (direct) {
@@ -1251,7 +1284,9 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 }
                 if (!partial) st_u(stage.idx(), g4, stage_key(bin, r_all, r_scat));
             }
-            if (!partial && tid == 0) tile_np[tile] = npend_r;
+            // stored paths of the tile: pass 1's own lie in slots [0, n); a partial tile's parked rays in the top *ccnt slots (the ranking pass
+            // writes the keys of those that go on, k_finish marks the ones that ended)
+            if (tid == 0) tile_np[tile] = npend_r | (partial ? *ccnt << 16 : 0);
             STAMP(4);
             if (MODE == 1 && *qcnt > QCAP - TILE) flushQueue(p, seg, qbuf, qcnt, qbase, tid);      // (uniform: the tile's last atomic on it lies before the ranking's barrier)
             continue;
@@ -1308,7 +1343,7 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             } else {
                 st_u(stage.idx(), gi4, (int32_t)-1);
             }
-            if (tid == 0) tile_np[tile] = npend;
+            if (tid == 0) tile_np[tile] = npend | ((MODE == 1 && pass1_partial) ? *ccnt << 16 : 0);
         }
         __syncthreads();
         STAMP(4);        // sort through LDS + stage write
@@ -1358,20 +1393,20 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         constexpr int MOVE_U = 4;                                     // tiles per step: their keys are requested before the first is used
         // (only the slots that hold a record are read: the tile's stored count, left by whoever finished the tile -- requested one step
         // ahead, so that the keys stay ONE round trip per step; the ranking pass of a later bounce wrote a key for every slot itself)
-        constexpr bool NP_ALL = MODE == 2 && !FIRST;
-        int np_next[MOVE_U];
+        int np_next[MOVE_U];                                          // (stored paths at the bottom of the tile | parked rays at its top << 16)
 #pragma unroll
-        for (int u = 0; u < MOVE_U; u++) np_next[u] = tile0 + u < tile1 ? (NP_ALL ? TILE : tile_np[tile0 + u]) : 0;
+        for (int u = 0; u < MOVE_U; u++) np_next[u] = tile0 + u < tile1 ? tile_np[tile0 + u] : 0;
         for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
             int32_t key[MOVE_U];
             int np_cur[MOVE_U];
 #pragma unroll
             for (int u = 0; u < MOVE_U; u++) {
                 np_cur[u] = np_next[u];
-                np_next[u] = tbase + MOVE_U + u < tile1 ? (NP_ALL ? TILE : tile_np[tbase + MOVE_U + u]) : 0;
+                np_next[u] = tbase + MOVE_U + u < tile1 ? tile_np[tbase + MOVE_U + u] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < MOVE_U; u++) key[u] = tid < np_cur[u] ? ld_u(keys, (uint32_t)((tbase + u) * TILE + tid) << 2) : -1;
+            for (int u = 0; u < MOVE_U; u++)
+                key[u] = (tid < (np_cur[u] & 0xffff) || tid >= TILE - (np_cur[u] >> 16)) ? ld_u(keys, (uint32_t)((tbase + u) * TILE + tid) << 2) : -1;
 #pragma unroll
             for (int u = 0; u < MOVE_U; u++) {
                 if (key[u] == -1) continue;
@@ -1599,6 +1634,7 @@ __global__ __launch_bounds__(256) void k_finish(const BounceParams p_in) {
             if (p.uses_uv) { st.u()[sa] = hit.u; st.v()[sa] = hit.v; }
             st.mg()[sa] = hit.mat | (hit.geom << 16);
         }
+        else if (PT_RANK_ONE_BARRIER) st.idx()[sa] = -1;           // (that form's tail reads the keys of every parked ray's slot: none here)
         st.lsrc()[owner] = K1_ALIVE | (pending ? K1_PEND : 0) | bin | ((sa & (TILE - 1)) << 16);
     }
 }
@@ -2548,7 +2584,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             const int mesh_gx = std::max(1, t->cus * (t->dbg_mesh_wg_per_cu > 0 ? t->dbg_mesh_wg_per_cu : PT_MESH_WG_PER_CU) / K);
             KT(2, { t->ks->mesh(first ? 1 : 0, dim3(mesh_gx, K), sizeof(int32_t) * ((size_t)t->bvh_stack * 256 + 32 * MESH_GEOM_WORDS), stream, &bp, t->bvh_stack);
                     t->ks->finish(first ? 1 : 0, dim3(std::max(1, grid / K), K), stream, &bp); });
-            const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + TILE);      // (ranking head + one key per slot)
+            const size_t lds_pass2 = sizeof(int32_t) * ((size_t)ldsHeadWords(nb) + std::max<size_t>(TILE, 2 * (size_t)WAVES * nb));      // (ranking head + the second histogram; one key per slot in the three-barrier form)
             KT(3, { int rcl = launch_bounce(t, first, 2, needs_albedo, dim3(gx_b, K), lds_pass2, stream, bp); if (rcl != PTX_OK) return rcl; });
         } else {
             bp.keys = nullptr; bp.items = nullptr; bp.item_count = nullptr; bp.item_cursor = nullptr; bp.seg_keys = bp.seg_items = 0; bp.tile_done = nullptr;
