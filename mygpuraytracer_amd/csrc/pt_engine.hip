@@ -78,6 +78,10 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
 #define PT_FAST_WAVES 8       // waves per SIMD the specialised k_bounce variants are compiled for (<= 64 registers; 8 workgroups'
                               // LDS is also what a CU holds with the Cornell tables since the record buffer lost a row and the window half its runs)
 #endif
+#ifndef PT_FAST_WAVES_FIRST
+#define PT_FAST_WAVES_FIRST 8      // the specialised camera-ray variant: 64 registers since round 5 (two values spill to scratch: the kernel alone +3 %, the wall with
+                                    // three launch sets in flight -0.8 %, three runs each on one box, gpurun_out/r5i_ab.log)
+#endif
 #ifndef PT_FAST_WAVES_SPLIT
 #define PT_FAST_WAVES_SPLIT 4 // same for the specialised MODE 1 variant, which carries the mesh candidate queue as well
 #endif
@@ -270,6 +274,12 @@ struct BounceParams {
     unsigned long long dir_bins;           // bit b: the records of material bin b carry the incoming direction (reflective, refractive, or a
                                            // material of an OBJ geom: what scatterRay reads it for); the other bins' records do not
     unsigned long long in_dir_bins, in_ntab_bins;      // dir_bins / ntab_bins of the launch that wrote `in` (the same, unless `in` is the cached camera bounce)
+    // The local index as ONE word per stored path (round 5), where a workgroup's chunk of the writing launch is at most 128 tiles (32 768
+    // slots; the host knows the bound: ceil(maxTiles / workgroups)): entry e = (slot - e) as 16 signed bits | the path's rank in its run
+    // << 16 -- slot and entry lie in the same chunk's region, so their distance fits, and so does a rank below the chunk's slots.  Half
+    // the index bytes: 4 B less read per ray, 4 B less written per stored path.  Larger chunks (8K frames with few iterations per set)
+    // keep the two words, lsrc and lidx.  idx16: what THIS launch's tail writes; in_idx16: what the launch that wrote `in` did.
+    int32_t idx16, in_idx16;
     unsigned long long ntab_bins;          // bit b: every hit of material bin b is a cube hit (no sphere or OBJ geom has the material): its records
                                            // carry the 3-bit code of the cube's tabulated normal in pix's bits 28-30 instead of the normal
     int32_t apps;                          // apps/src variant: radiance * PI at gather, albedo AOV on iteration 1
@@ -665,7 +675,7 @@ __device__ __forceinline__ void flushQueue(const BounceParams &p, int seg, const
 // (enqueue_batch); everything else takes the general kernel, same results.  For the two halves of the split bounce (MODE 1, 2)
 // FAST bakes only the subset that textured scenes with BVH meshes satisfy as well.
 template <bool FIRST, int MODE, bool FAST = false>
-__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : FIRST ? PT_FAST_WAVES - 1 : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {      // (the camera-ray
+__global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST_WAVES_SPLIT : MODE == 2 ? PT_FAST_WAVES_SPLIT2 : FIRST ? PT_FAST_WAVES_FIRST : PT_FAST_WAVES) void k_bounce(const BounceParams p_in) {      // (the camera-ray
                                                                                    // variant needs 65 registers: seven waves without spilling)
 #ifdef PT_WGCLOCK
     const unsigned long long wg_t0 = wall_clock64();       // 100 MHz: latency of the workgroup's phases (prologue, tile loop, tail)
@@ -846,10 +856,12 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         const PathSoA in = soa_fresh(in_k);
         // the sorted stream is not materialised: its position is entry li of the previous bounce's local index, which names the
         // slot of that bounce's stage and the path's rank inside its run
-        const uint32_t j = (uint32_t)ld_u(in.lsrc(), li4);
+        const uint32_t w = (uint32_t)ld_u(in.lsrc(), li4);
+        uint32_t j;
+        if (p.in_idx16) { j = (li4 >> 2) + (uint32_t)(int32_t)(int16_t)(w & 0xffffu); r.idx = idx_base + (int)(w >> 16); }
+        else { j = w; r.idx = idx_base + ld_u(in.lidx(), li4); }
         if (__builtin_expect(j >= p.fence_slots, 0)) fence_report(p);
         const uint32_t j4 = min(j, p.fence_slots - 1u) << 2;
-        r.idx = idx_base + ld_u(in.lidx(), li4);
         const bool with_dir = (uint32_t)(jp - dir_lo0) < (uint32_t)dir_len0 || (uint32_t)(jp - dir_lo1) < (uint32_t)dir_len1;
         const bool coded_n = (uint32_t)(jp - ntab_lo0) < (uint32_t)ntab_len0 || (uint32_t)(jp - ntab_lo1) < (uint32_t)ntab_len1;
         typedef float quad __attribute__((ext_vector_type(4)));
@@ -1251,7 +1263,8 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
             __syncthreads();
             // (stored paths fill the slots from the bottom -- pass 1's records and k_finish's parked ones are not contiguous: keys for every slot)
             st_u(soa_fresh(stage_k).idx(), (uint32_t)i << 2, keybuf[tid]);
-            if (tid == 0) tile_np[tile] = TILE;                   // (this form writes a key for every slot)
+            if (FIRST && tid == 0) tile_np[tile] = TILE;          // (this form writes a key for every slot; the camera bounce's tail looks the counts
+                                                                  // up -- the tiles pass 1 finished have fewer keys --, a later bounce's knows)
             continue;
         }
         if (direct) {
@@ -1393,16 +1406,18 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
         constexpr int MOVE_U = 4;                                     // tiles per step: their keys are requested before the first is used
         // (only the slots that hold a record are read: the tile's stored count, left by whoever finished the tile -- requested one step
         // ahead, so that the keys stay ONE round trip per step; the ranking pass of a later bounce wrote a key for every slot itself)
+        // (the three-barrier ranking pass of a later bounce wrote a key for every slot of every tile: nothing to look up)
+        constexpr bool NP_ALL = MODE == 2 && !FIRST && !PT_RANK_ONE_BARRIER;
         int np_next[MOVE_U];                                          // (stored paths at the bottom of the tile | parked rays at its top << 16)
 #pragma unroll
-        for (int u = 0; u < MOVE_U; u++) np_next[u] = tile0 + u < tile1 ? tile_np[tile0 + u] : 0;
+        for (int u = 0; u < MOVE_U; u++) np_next[u] = tile0 + u < tile1 ? (NP_ALL ? TILE : tile_np[tile0 + u]) : 0;
         for (int tbase = tile0; tbase < tile1; tbase += MOVE_U) {
             int32_t key[MOVE_U];
             int np_cur[MOVE_U];
 #pragma unroll
             for (int u = 0; u < MOVE_U; u++) {
                 np_cur[u] = np_next[u];
-                np_next[u] = tbase + MOVE_U + u < tile1 ? tile_np[tbase + MOVE_U + u] : 0;
+                np_next[u] = tbase + MOVE_U + u < tile1 ? (NP_ALL ? TILE : tile_np[tbase + MOVE_U + u]) : 0;
             }
 #pragma unroll
             for (int u = 0; u < MOVE_U; u++)
@@ -1414,8 +1429,12 @@ __global__ __launch_bounds__(TILE, !FAST ? PT_BOUNCE_WAVES : MODE == 1 ? PT_FAST
                 const int bin = key[u] & ((1 << BIN_BITS) - 1), r_all = (key[u] >> BIN_BITS) & (TILE - 1), r_scat = (int)((uint32_t)key[u] >> (BIN_BITS + RANK_BITS));
                 const uint32_t c4 = (uint32_t)(bin * p.maxTiles + tile) << 2;      // (a segment's table is below 4 GiB: ptx_create)
                 const int pos = tile0 * TILE + cbb[bin] + ld_u(counts_scat, c4) + r_scat;
-                st_u(stage.lsrc(), (uint32_t)pos << 2, (int32_t)(tile * TILE + tid));
-                st_u(stage.lidx(), (uint32_t)pos << 2, (int32_t)(ld_u(counts_all, c4) + r_all));
+                const int slot = tile * TILE + tid, rank = ld_u(counts_all, c4) + r_all;
+                if (p.idx16) st_u(stage.lsrc(), (uint32_t)pos << 2, (int32_t)(((uint32_t)(slot - pos) & 0xffffu) | ((uint32_t)rank << 16)));
+                else {
+                    st_u(stage.lsrc(), (uint32_t)pos << 2, (int32_t)slot);
+                    st_u(stage.lidx(), (uint32_t)pos << 2, (int32_t)rank);
+                }
             }
         }
     }
@@ -1649,7 +1668,7 @@ __global__ void k_capture_prefix(const int32_t *chunk, int chunk_cap, int nruns,
     gs[nruns] = s; ga[nruns] = a;
 }
 __global__ void k_capture(PathSoA stage, const int32_t *chunk, int chunk_cap, int nruns, const int32_t *gs, const int32_t *ga, int cap,
-                          int32_t *out_i, float *out_f) {
+                          int32_t *out_i, float *out_f, int idx16) {
     const int n = min(gs[nruns], cap);
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         int lo = 0, hi = nruns - 1;                              // last run that starts at or before k
@@ -1658,9 +1677,11 @@ __global__ void k_capture(PathSoA stage, const int32_t *chunk, int chunk_cap, in
             if (gs[mid] <= k) lo = mid; else hi = mid - 1;
         }
         const int li = chunk[2 * chunk_cap + lo] + (k - gs[lo]);
-        int j = stage.lsrc()[li];
+        const uint32_t w = (uint32_t)stage.lsrc()[li];
+        int j = idx16 ? li + (int)(int16_t)(w & 0xffffu) : (int)w;
+        const int rank = idx16 ? (int)(w >> 16) : stage.lidx()[li];
         j = j < 0 ? 0 : (j >= cap ? cap - 1 : j);
-        out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = ga[lo] + stage.lidx()[li]; out_i[2 * (size_t)cap + k] = stage.mg()[j];
+        out_i[k] = stage.pix()[j]; out_i[(size_t)cap + k] = ga[lo] + rank; out_i[2 * (size_t)cap + k] = stage.mg()[j];
         for (int f = 0; f < SOA_LOGICAL_FLOATS; f++) out_f[(size_t)f * cap + k] = stage.fieldAt(f, (size_t)j);
     }
 }
@@ -2079,6 +2100,7 @@ struct ptx_tracer {
     unsigned long long dir_bins = ~0ull;                 // BounceParams::dir_bins (all ones: every record carries its direction)
     unsigned long long ntab_bins = 0ull;                 // BounceParams::ntab_bins (none: every record carries its normal)
     unsigned long long cache_dir_bins = ~0ull, cache_ntab_bins = 0ull;      // ... as the cached camera bounce was written
+    int cache_idx16 = 0;                                                    // ... and its local index (BounceParams::idx16)
     uchar4 *d_pbo = nullptr;                             // ptx_write_pbo's device staging (allocated on first use)
     float *d_denoised = nullptr;                         // ptx_write_denoised_pbo_device's copy of the host frame (first use)
     float *d_albedo = nullptr;                           // apps variant only: W*H*3
@@ -2552,6 +2574,10 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
         // (the masks tell the READER of a stage what its records hold; a launch that WRITES with other masks than it reads with -- a cached
         // camera bounce replayed while a debug capture has switched them off, or the other way round -- gets both: in_* for what it reads)
         bp.in_dir_bins = from_cache ? t->cache_dir_bins : bp.dir_bins; bp.in_ntab_bins = from_cache ? t->cache_ntab_bins : bp.ntab_bins;
+        // (one-word local index where no workgroup's chunk can pass 128 tiles: this launch's, and that of the launch whose stage it reads)
+        auto idx16_of = [&](int gxw) { return (!getenv("PTX_DEBUG_NO_IDX16") && (t->maxTiles + gxw - 1) / std::max(gxw, 1) <= 128) ? 1 : 0; };
+        bp.idx16 = idx16_of(first ? gx_first : gx_later);
+        bp.in_idx16 = first ? 0 : from_cache ? t->cache_idx16 : idx16_of(b == 1 ? gx_first : gx_later);
         bp.nbins = nb; bp.maxTiles = t->maxTiles;
         bp.counts_all = counts_all; bp.counts_scat = counts_scat;
         bp.chunk = to_cache ? t->d_cache_chunk : chunks(b); bp.chunk_cap = (int32_t)chunk_cap;
@@ -2595,7 +2621,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             HIPCHECK(hipMemcpyAsync(t->d_cache_totals, totals(0, 0), sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToDevice, stream));
             HIPCHECK(hipMemcpyAsync(t->d_cache_super, supers(0, 0), sizeof(int32_t) * 2 * nb * t->nsuper, hipMemcpyDeviceToDevice, stream));
             t->cache_gx = gx_b;
-            t->cache_dir_bins = bp.dir_bins; t->cache_ntab_bins = bp.ntab_bins;
+            t->cache_dir_bins = bp.dir_bins; t->cache_ntab_bins = bp.ntab_bins; t->cache_idx16 = bp.idx16;
             t->cache_valid = true;
         }
         if (t->capture_bounce == b && t->d_cap && b + 1 < t->traceDepth) {       // K == 1 here (see ptx_render)
@@ -2603,7 +2629,7 @@ int enqueue_batch(ptx_tracer *t, int iter_first, int K, int stride = 1, int lane
             int32_t *gs = t->d_cap + 3 * (size_t)t->cap + nb, *ga = gs + chunk_cap + 1;
             hipLaunchKernelGGL(k_capture_prefix, dim3(1), dim3(64), 0, stream, bp.chunk, (int)chunk_cap, nb * gx_b, gs, ga);
             hipLaunchKernelGGL(k_capture, dim3(std::min(1024, (t->cap + 255) / 256)), dim3(256), 0, stream, bp.stage, bp.chunk, (int)chunk_cap,
-                               nb * gx_b, gs, ga, t->cap, t->d_cap, t->d_cap_f);
+                               nb * gx_b, gs, ga, t->cap, t->d_cap, t->d_cap_f, bp.idx16);
             HIPCHECK(hipMemcpyAsync(t->d_cap + 3 * (size_t)t->cap, totals(b, 1), sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, stream));
             t->cap_filled = true;
         }
