@@ -262,6 +262,10 @@ int ptx_get_kernel_times(ptx_tracer *t, double ms_by_kind[4], int64_t launches_b
 /* ---- per-stage entry points (parity tests; same record layouts as the reference's PathSegment 44 B and
  *      ShadeableIntersection 32 B, host arrays in/out, the work runs on the device) --------------------------- */
 int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out10);
+/* objTriIntersectionTest / triangleIntersectionLocalTest, src/intersections.h:175-205, 284-315: dead code in the reference (its call is
+ * commented out, src/pathtrace.cu:313) and on no path here; a known-answer entry point only.  out8 per ray: t (object space), world
+ * point, world normal, outside.  Non-OBJ geoms give t = -1. */
+int ptx_kat_obj_tri_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out8);
 int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32);
 /* computeIntersections (src/pathtrace.cu:261-344) through the functions the bounce kernels really run -- candidate masks from the
  * world boxes, the tile's (ray, geom) pairs tested by the key functions, 64-bit minimum, winner decoded (split != 0: the three

@@ -215,6 +215,7 @@ def load_library():
     L.ptx_get_kernel_times.restype, L.ptx_get_kernel_times.argtypes = i, [vp, vp, vp]
     L.ptx_kat_geom_test.restype, L.ptx_kat_geom_test.argtypes = i, [vp, i, i, vp, vp]
     L.ptx_kat_compute_intersections.restype, L.ptx_kat_compute_intersections.argtypes = i, [vp, i, vp, vp]
+    L.ptx_kat_obj_tri_test.restype, L.ptx_kat_obj_tri_test.argtypes = i, [vp, i, i, vp, vp]
     L.ptx_kat_tile_intersect.restype, L.ptx_kat_tile_intersect.argtypes = i, [vp, i, vp, vp, i]
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
     L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
@@ -674,6 +675,13 @@ class Tracer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((len(rays), 10), np.float32)
         _check(self.lib.ptx_kat_geom_test(self.h, gi, len(rays), _ptr(rays), _ptr(out)), "ptx_kat_geom_test")
+        return out
+
+    def obj_tri_test(self, gi, rays):
+        """objTriIntersectionTest of the reference (src/intersections.h:284-315, dead code there) on OBJ geom gi: (n, 8) = t, point, normal, outside"""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 8), np.float32)
+        _check(self.lib.ptx_kat_obj_tri_test(self.h, gi, len(rays), _ptr(rays), _ptr(out)), "ptx_kat_obj_tri_test")
         return out
 
     def compute_intersections(self, paths):

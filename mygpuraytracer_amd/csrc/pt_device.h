@@ -973,6 +973,46 @@ struct Hit {
                       // a stored path of a cubes-only material carries instead of the normal itself (cubeNormalByCode); 0 for every other hit
 };
 
+// triangleIntersectionLocalTest + objTriIntersectionTest, src/intersections.h:175-205, 284-315 -- DEAD CODE in the reference (the
+// only call is commented out, src/pathtrace.cu:313) and on no path here either: restated as a known-answer function for SURVEY 8(a10)
+// (ptx_kat_obj_tri_test; goldens produced by calling the reference's own functions, tests/golden/dead_tri_kat.npz).  Plane hit, then the
+// three sub-triangle areas against the triangle's; nearest face by OBJECT-space distance, which is also what it returns.
+PT_DEV float triangleLocalTest(vec3 ro, vec3 rd, vec3 v0, vec3 v1, vec3 v2, vec3 &intersectionPoint, vec3 &normal) {
+    const vec3 planeNormal = normalize(cross(sub(v1, v0), sub(v2, v0)));
+    const float t = dot(planeNormal, sub(v0, ro)) / dot(planeNormal, rd);
+    if (t < 0) return -1.f;
+    const vec3 p = add(ro, scale(rd, t));
+    const float S = 0.5f * length(cross(sub(v0, v1), sub(v0, v2)));
+    const float s1 = 0.5f * length(cross(sub(p, v1), sub(p, v2))) / S;
+    const float s2 = 0.5f * length(cross(sub(p, v2), sub(p, v0))) / S;
+    const float s3 = 0.5f * length(cross(sub(p, v0), sub(p, v1))) / S;
+    const float sum = s1 + s2 + s3;
+    if (s1 >= 0 && s1 <= 1 && s2 >= 0 && s2 <= 1 && s3 >= 0 && s3 <= 1 && __builtin_fabsf(sum - 1.0f) < 1.1920928955078125e-07f) {
+        intersectionPoint = p;
+        normal = planeNormal;
+        return t;
+    }
+    return -1.f;
+}
+PT_DEV float objTriTest(const DScene &sc, const DGeom &geom, Ray r, vec3 &intersectionPoint, vec3 &normal, bool &outside) {
+    float min_tri_t = 3.402823466e+38f;
+    vec3 tmp_i = V3(0.f, 0.f, 0.f), tmp_n = V3(0.f, 0.f, 0.f), min_i = V3(0.f, 0.f, 0.f), min_n = V3(0.f, 0.f, 0.f);
+    int nearest = -1;
+    Ray q;
+    q.o = multiplyMV(geom.inv, r.o, 1.0f);
+    q.d = normalize(multiplyMV(geom.inv, r.d, 0.0f));
+    for (int j = 0; j < geom.faceCount; j++) {
+        const float *tri = sc.faces + (size_t)(geom.faceStart + j) * 15;
+        const float tt = triangleLocalTest(q.o, q.d, V3(tri[0], tri[1], tri[2]), V3(tri[5], tri[6], tri[7]), V3(tri[10], tri[11], tri[12]), tmp_i, tmp_n);
+        if (tt > 0 && tt < min_tri_t) { min_i = tmp_i; min_n = tmp_n; min_tri_t = tt; nearest = j; }
+    }
+    if (nearest == -1) return -1.f;
+    intersectionPoint = multiplyMV(geom.xf, min_i, 1.f);
+    normal = normalize(multiplyMV(geom.invT, min_n, 0.f));
+    outside = dot(normal, r.d) < 0;
+    return min_tri_t;
+}
+
 // Header of geom i (transform, inverseTransform, type, material, face range) through the SCALAR memory path: the
 // index is wave-uniform and the table is immutable while a kernel runs, so reading it as constant address space
 // lets the compiler use s_load and keep the matrices in SGPRs instead of one VGPR copy per lane.

@@ -1800,6 +1800,19 @@ __global__ void k_kat_geom(DScene sc, int gi, int n, const float *rays, float *o
     o[9] = outside ? 1.f : 0.f;
 }
 
+// the reference's dead objTriIntersectionTest (src/intersections.h:284-315) on an OBJ geom: out per ray = t, point, normal, outside
+__global__ void k_kat_obj_tri(DScene sc, int gi, int n, const float *rays, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DGeom &g = sc.geoms[gi];
+    Ray r; r.o = ld3(rays + i * 6); r.d = ld3(rays + i * 6 + 3);
+    vec3 p = V3(0, 0, 0), nrm = V3(0, 0, 0);
+    bool outside = true;
+    const float t = g.type == G_OBJ ? objTriTest(sc, g, r, p, nrm, outside) : -1.f;
+    float *o = out + i * 8;
+    o[0] = t; o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = nrm.x; o[5] = nrm.y; o[6] = nrm.z; o[7] = outside ? 1.f : 0.f;
+}
+
 __global__ void k_kat_intersect(DScene sc, int n, const HostPath *paths, HostIsect *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1962,6 +1975,7 @@ struct KernelSet {
     void (*finish)(int first, dim3 grid, hipStream_t st, const void *bounce_params);
     void (*kat_geom)(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out);
     void (*kat_intersect)(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out);
+    void (*kat_obj_tri)(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out);
     void (*kat_tile)(int split, dim3 grid, size_t lds, hipStream_t st, const void *sc, const void *scg, int n, const void *paths, void *out, int uses_uv);
     void (*kat_shade)(dim3 grid, hipStream_t st, const void *scene, int iter, int n, const int32_t *idx, const void *isects, void *paths);
     void (*kat_generate)(dim3 grid, hipStream_t st, const void *cam, int iter, int traceDepth, int aa, int dof, void *paths);
@@ -1998,6 +2012,9 @@ void ks_finish(int first, dim3 grid, hipStream_t stream, const void *params) {
 void ks_kat_geom(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out) {
     hipLaunchKernelGGL(k_kat_geom, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), gi, n, rays, out);
 }
+void ks_kat_obj_tri(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out) {
+    hipLaunchKernelGGL(k_kat_obj_tri, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), gi, n, rays, out);
+}
 void ks_kat_intersect(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out) {
     hipLaunchKernelGGL(k_kat_intersect, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), n, static_cast<const HostPath *>(paths), static_cast<HostIsect *>(out));
 }
@@ -2015,7 +2032,7 @@ void ks_kat_generate(dim3 grid, hipStream_t st, const void *cam, int iter, int t
 void ks_kat_libm(dim3 grid, hipStream_t st, int n, const float *x, float *s, float *c, const double *pw, double *p5, const float *pxy, float *pout) {
     hipLaunchKernelGGL(k_kat_libm, grid, dim3(256), 0, st, n, x, s, c, pw, p5, pxy, pout);
 }
-const KernelSet g_kernels_here = {PT_ARITH, ks_bounce, ks_mesh, ks_finish, ks_kat_geom, ks_kat_intersect, ks_kat_tile, ks_kat_shade, ks_kat_generate, ks_kat_libm};
+const KernelSet g_kernels_here = {PT_ARITH, ks_bounce, ks_mesh, ks_finish, ks_kat_geom, ks_kat_intersect, ks_kat_obj_tri, ks_kat_tile, ks_kat_shade, ks_kat_generate, ks_kat_libm};
 
 }  // namespace
 
@@ -3513,6 +3530,20 @@ int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float 
     { const DScene sc = t->scene(); t->ks->kat_geom(dim3((n + 255) / 256), t->stream, &sc, geom, n, d_in, d_out); }
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(out10, d_out, sizeof(float) * 10 * (size_t)n, hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_kat_obj_tri_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out8) {
+    KAT_PROLOGUE
+    if (geom < 0 || geom >= t->ngeoms) return set_error(PTX_ERR_INVALID, "geom index out of range");
+    if (n <= 0) return PTX_OK;
+    DevBuf<float> d_in; DevBuf<float> d_out;
+    HIPCHECK(hipMalloc(&d_in.p, sizeof(float) * 6 * (size_t)n));
+    HIPCHECK(hipMalloc(&d_out.p, sizeof(float) * 8 * (size_t)n));
+    HIPCHECK(hipMemcpy(d_in, rays6, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
+    { const DScene sc = t->scene(); t->ks->kat_obj_tri(dim3((n + 255) / 256), t->stream, &sc, geom, n, d_in.p, d_out.p); }
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(out8, d_out, sizeof(float) * 8 * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
 }
 

@@ -514,6 +514,67 @@ static float meshIntersectionTest(const o_geom *geom, o_ray r, v3 *intersectionP
     return tmin;
 }
 
+/* triangleIntersectionLocalTest, src/intersections.h:175-205 -- DEAD CODE in the reference (its only caller is objTriIntersectionTest,
+ * whose call in computeIntersections is commented out, src/pathtrace.cu:313).  Restated for SURVEY 8(a10) as a known-answer function
+ * only; nothing on the path calls it.  Plane hit by the ray, then the three sub-triangle areas against the triangle's. */
+static float triangleIntersectionLocalTest(v3 ro, v3 rd, v3 v0, v3 v1, v3 v2, v3 *intersectionPoint, v3 *normal) {
+    v3 planeNormal = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+    float t = dot3(planeNormal, sub3(v0, ro)) / dot3(planeNormal, rd);
+    if (t < 0) return -1;
+    v3 p = add3(ro, scale3(rd, t));                       /* ro + t * rd */
+    float S = 0.5f * length3(cross3(sub3(v0, v1), sub3(v0, v2)));
+    float s1 = 0.5f * length3(cross3(sub3(p, v1), sub3(p, v2))) / S;
+    float s2 = 0.5f * length3(cross3(sub3(p, v2), sub3(p, v0))) / S;
+    float s3 = 0.5f * length3(cross3(sub3(p, v0), sub3(p, v1))) / S;
+    float sum = s1 + s2 + s3;
+    if (s1 >= 0 && s1 <= 1 && s2 >= 0 && s2 <= 1 && s3 >= 0 && s3 <= 1 && fabsf(sum - 1.0f) < FLT_EPSILON) {
+        *intersectionPoint = p;
+        *normal = planeNormal;
+        return t;
+    }
+    return -1;
+}
+
+/* objTriIntersectionTest, src/intersections.h:284-315 (dead, see above): nearest face by the local test in object space; returns the
+ * OBJECT-space distance (unlike meshIntersectionTest), the world-space point and normal of that face. */
+static float objTriIntersectionTest(const o_geom *geom, o_ray r, v3 *intersectionPoint, v3 *normal, int *outside) {
+    float min_tri_t = FLT_MAX;
+    v3 tmp_tri_intersect = V3(0, 0, 0), tmp_tri_normal = V3(0, 0, 0), min_tri_intersect = V3(0, 0, 0), min_tri_normal = V3(0, 0, 0);
+    int nearest = -1;
+    o_ray q;
+    q.origin = multiplyMV(geom->inverseTransform, r.origin, 1.0f);
+    q.direction = normalize3(multiplyMV(geom->inverseTransform, r.direction, 0.0f));
+    for (int j = 0; j < geom->faceSize; j++) {
+        const float *tri = geom->faces + j * 15;
+        float tmp_tri_t = triangleIntersectionLocalTest(q.origin, q.direction, ld3(tri), ld3(tri + 5), ld3(tri + 10), &tmp_tri_intersect, &tmp_tri_normal);
+        if (tmp_tri_t > 0 && tmp_tri_t < min_tri_t) {
+            min_tri_intersect = tmp_tri_intersect;
+            min_tri_normal = tmp_tri_normal;
+            min_tri_t = tmp_tri_t;
+            nearest = j;
+        }
+    }
+    if (nearest == -1) return -1;
+    *intersectionPoint = multiplyMV(geom->transform, min_tri_intersect, 1.f);
+    *normal = normalize3(multiplyMV(geom->invTranspose, min_tri_normal, 0.f));
+    *outside = dot3(*normal, r.direction) < 0;
+    return min_tri_t;
+}
+
+/* out per ray: t, point(3), normal(3), outside = 8 floats (point / normal / outside as they were passed in when there is no hit: 0, 0, 1) */
+void o_obj_tri_test(void *h, int gi, int n, const float *rays6, float *out8) {
+    o_scene *s = (o_scene *)h;
+    const o_geom *g = &s->geoms[gi];
+    for (int i = 0; i < n; i++) {
+        o_ray r; r.origin = ld3(rays6 + i * 6); r.direction = ld3(rays6 + i * 6 + 3);
+        v3 p = V3(0, 0, 0), nrm = V3(0, 0, 0);
+        int outside = 1;
+        float t = objTriIntersectionTest(g, r, &p, &nrm, &outside);
+        float *o = out8 + i * 8;
+        o[0] = t; st3(o + 1, p); st3(o + 4, nrm); o[7] = outside ? 1.f : 0.f;
+    }
+}
+
 void o_geom_test(void *h, int gi, int n, const float *rays6, float *out10) {
     o_scene *s = (o_scene *)h;
     const o_geom *g = &s->geoms[gi];

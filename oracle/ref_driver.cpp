@@ -248,6 +248,22 @@ void ref_geom_test(void *h, int gi, int n, const float *rays, float *out) {
     }
 }
 
+// the reference's dead pair (src/intersections.h:175-205, 284-315), called as it stands.  out per ray: t, point(3), normal(3), outside
+void ref_obj_tri_test(void *h, int gi, int n, const float *rays, float *out) {
+    RefState *st = (RefState *)h;
+    const Geom &g = st->geoms[gi];
+    for (int i = 0; i < n; i++) {
+        Ray r;
+        memcpy(&r.origin, rays + i * 6, 12);
+        memcpy(&r.direction, rays + i * 6 + 3, 12);
+        glm::vec3 p(0.f), nrm(0.f);
+        bool outside = true;
+        float t = g.type == OBJ ? objTriIntersectionTest(g, r, p, nrm, outside) : -1.f;
+        float *o = out + i * 8;
+        o[0] = t; memcpy(o + 1, &p, 12); memcpy(o + 4, &nrm, 12); o[7] = outside ? 1.f : 0.f;
+    }
+}
+
 // body of computeIntersections (pathtrace.cu:270-343) for one path
 static void compute_intersection_one(const std::vector<Geom> &geoms_v, const PathSegment &pathSegment,
                                      ShadeableIntersection &dst) {

@@ -60,6 +60,7 @@ class _Tracer:
             "rng_raw": (None, [i, i, i, i, vp]),
             "rng_uniform": (None, [i, i, i, f, f, i, vp]),
             "geom_test": (None, [vp, i, i, vp, vp]),
+            "obj_tri_test": (None, [vp, i, i, vp, vp]),
             "compute_intersections": (None, [vp, i, vp, vp]),
             "shade": (None, [vp, i, i, i, vp, vp, vp]),
             "pt_init": (None, [vp]),
@@ -98,6 +99,13 @@ class _Tracer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((len(rays), 10), np.float32)
         self._f("geom_test")(self.h, gi, len(rays), _ptr(rays), _ptr(out))
+        return out
+
+    def obj_tri_test(self, gi, rays):
+        """objTriIntersectionTest (src/intersections.h:284-315, dead code of the reference) on an OBJ geom: (n, 8) = t, point, normal, outside"""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 8), np.float32)
+        self._f("obj_tri_test")(self.h, gi, len(rays), _ptr(rays), _ptr(out))
         return out
 
     def compute_intersections(self, paths):

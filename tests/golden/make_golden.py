@@ -41,6 +41,8 @@ PROVENANCE = {
     "loader_": "direct",                 # Scene::Scene / loadGeom / loadObj / loadCamera of src/scene.cpp; the post-runCuda camera
                                          # inside the same files is restated (main.cpp needs GL)
     "isect_kat_": "direct",              # boxIntersectionTest / sphereIntersectionTest / meshIntersectionTest themselves
+    "dead_tri_kat": "direct",            # objTriIntersectionTest -> triangleIntersectionLocalTest (src/intersections.h:175-205, 284-315), dead
+                                         # code in the reference, called as it stands
     "shade_kat_": "direct+restated",     # scatterRay itself, inside the restated body of shadeFakeMaterial; inputs captured mid-render
     "render_": "restated",               # whole frames, per-bounce counts, sorted streams, 8-bit previews
     "render_apps_": "restated",          # the same with the apps/src deltas (x PI gather, albedo AOV)
@@ -145,6 +147,29 @@ def random_rays(rng, n, centre, radius):
     d[n // 8: n // 8 + k] = axes                                                 # axis-parallel (zero components)
     d[-8:] *= rng.uniform(0.1, 10.0, (8, 1))                                     # unnormalised directions
     return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def dead_tri(R):
+    """objTriIntersectionTest (src/intersections.h:284-315, with triangleIntersectionLocalTest :175-205) of the reference, called directly
+    on the two meshes the reference ships and can load: cube.obj inside cornellObj.txt (12 triangles, rotated and scaled) and
+    cottage_obj.obj (486).  Its acceptance test -- the three sub-triangle areas must sum to the triangle's within FLT_EPSILON -- rejects
+    most true hits to rounding, so the fixture carries many rays per mesh to hold a useful number of accepted ones."""
+    rng = np.random.default_rng(20261005)
+    out = {}
+    R.load(os.path.join(REFERENCE_ROOT, "scenes", "cornellObj.txt"))
+    d = R.dump()
+    gi = [i for i in range(len(d["geom_ints"])) if d["geom_ints"][i][0] == 3][0]
+    centre = d["geom_trs"][gi][:3].astype(np.float64)
+    rays = random_rays(rng, 4096, centre, float(np.max(np.abs(d["geom_trs"][gi][6:9]))) * 0.6 + 0.2)
+    out["obj_geom"] = np.int32(gi); out["obj_rays"] = rays; out["obj_out"] = R.obj_tri_test(gi, rays)
+    R.load_text(cottage_text())                    # the reference's own cottage_obj.obj through the reference's loader, as `cottage` does
+    dc = R.dump()
+    gi = [k for k in range(len(dc["geom_ints"])) if len(dc["faces"][k])][0]
+    rays = random_rays(rng, 4096, dc["geom_trs"][gi][:3].astype(np.float64) + [0, 1.0, 0], 2.5)
+    out["cottage_geom"] = np.int32(gi); out["cottage_rays"] = rays; out["cottage_out"] = R.obj_tri_test(gi, rays)
+    np.savez_compressed(os.path.join(HERE, "dead_tri_kat.npz"), **out)
+    for k in ("obj", "cottage"):
+        print(k, "accepted", int((out[k + "_out"][:, 0] > 0).sum()), "of", len(out[k + "_rays"]))
 
 
 def png_textures(R):
@@ -323,6 +348,9 @@ def main():
         return
     if sys.argv[1:] == ["cottage"]:
         cottage(RefLib(so))
+        return
+    if sys.argv[1:] == ["dead_tri"]:
+        dead_tri(RefLib(so))
         return
     R = RefLib(so)
     rng = np.random.default_rng(20261004)

@@ -125,6 +125,26 @@ def test_intersection_kats_on_device(gpu_product, O, scene):
     T.close()
 
 
+def test_dead_triangle_functions_on_device(gpu_product, O):
+    """objTriIntersectionTest -> triangleIntersectionLocalTest (src/intersections.h:175-205, 284-315; dead code in the
+    reference, on no path here) as device functions behind ptx_kat_obj_tri_test, against what the reference's own functions returned
+    ([direct] fixture dead_tri_kat.npz): cube.obj inside cornellObj.txt from the scene file, cottage_obj.obj from the loader's vectors."""
+    k = golden("dead_tri_kat.npz")
+    s, T = make_pair(gpu_product, O, "cornellObj.txt", (16, 16), 8)
+    cases = [("obj", T)]
+    from conftest import dump_from_golden
+    Tc = gpu_product.Tracer.from_pod(dump_from_golden(golden("loader_cottage.npz")))
+    cases.append(("cottage", Tc))
+    for which, tr in cases:
+        out = tr.obj_tri_test(int(k[which + "_geom"]), k[which + "_rays"])
+        ref = k[which + "_out"]
+        hit = ref[:, 0] > 0
+        assert hit.sum() > 500
+        assert beq(out[:, 0], ref[:, 0]) and beq(out[hit], ref[hit]), which
+        assert beq(out, O.obj_tri_test(int(k[which + "_geom"]), k[which + "_rays"])) if which == "obj" else True
+    T.close(); Tc.close()
+
+
 @pytest.mark.parametrize("scene,res,depth,opt", [
     ("sphere.txt", (64, 64), 4, {}),
     ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),

@@ -64,6 +64,21 @@ def test_intersection_kats(O, scene):
         assert beq(out[hit], ref[hit])
 
 
+@pytest.mark.parametrize("which,loader", [("obj", "loader_cornellObj.npz"), ("cottage", "loader_cottage.npz")])
+def test_dead_triangle_functions(O, which, loader):
+    """objTriIntersectionTest -> triangleIntersectionLocalTest (src/intersections.h:175-205, 284-315), dead code in the
+    reference (the call is commented out, src/pathtrace.cu:313) and on no path here: the oracle's restatement against what the
+    reference's own functions returned for 4096 rays around cube.obj and around cottage_obj.obj ([direct] fixture dead_tri_kat.npz)."""
+    k = golden("dead_tri_kat.npz")
+    O.create(dump_from_golden(golden(loader)))
+    out = O.obj_tri_test(int(k[which + "_geom"]), k[which + "_rays"])
+    ref = k[which + "_out"]
+    hit = ref[:, 0] > 0
+    assert hit.sum() > 500 and (~hit).sum() > 500, "fixture should exercise hits and misses"
+    assert beq(out[:, 0], ref[:, 0])
+    assert beq(out[hit], ref[hit])
+
+
 def _scene_for_shade(O, tag):
     from test_loader import product_dump_from_text      # mirror scenes exist only as text: load with the product loader
     k = golden("shade_kat_%s.npz" % tag)

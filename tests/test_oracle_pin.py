@@ -113,3 +113,22 @@ def test_cottage_mesh_loader_oracle_and_bvh(ref_lib, oracle_lib, product, tmp_pa
     rays = np.concatenate([rays_around(rng, 20000, 3 * ext, ext), rays_around(rng, 5000, 0.3 * ext, ext)])
     fl, tl, fb, tb, st = run_check(product, faces, rays)
     assert beq(fl, fb) and beq(tl, tb) and (fl >= 0).sum() > 2000
+
+
+def test_dead_triangle_functions_live(ref_lib, oracle_lib):
+    """SURVEY 8(a10) on fresh rays: the reference's own objTriIntersectionTest (src/intersections.h:284-315, dead code there) against
+    the oracle's restatement, 20 000 rays around cube.obj in cornellObj.txt -- bit for bit, hits and misses."""
+    _pair(ref_lib, oracle_lib, "cornellObj.txt", (32, 32), 4, 0)
+    d = ref_lib.dump()
+    gi = [i for i in range(len(d["geom_ints"])) if d["geom_ints"][i][0] == 3][0]
+    rng = np.random.default_rng(77)
+    centre = d["geom_trs"][gi][:3].astype(np.float64)
+    o = centre + rng.normal(size=(20000, 3)) * 3.0
+    t = centre + rng.normal(size=(20000, 3)) * 0.8
+    dirs = t - o
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    rays = np.concatenate([o, dirs], 1).astype(np.float32)
+    a, b = ref_lib.obj_tri_test(gi, rays), oracle_lib.obj_tri_test(gi, rays)
+    assert (a[:, 0] > 0).sum() > 2000
+    assert beq(a, b)
+
