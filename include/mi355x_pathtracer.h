@@ -266,6 +266,10 @@ int ptx_kat_geom_test(ptx_tracer *t, int geom, int n, const float *rays6, float 
  * commented out, src/pathtrace.cu:313) and on no path here; a known-answer entry point only.  out8 per ray: t (object space), world
  * point, world normal, outside.  Non-OBJ geoms give t = -1. */
 int ptx_kat_obj_tri_test(ptx_tracer *t, int geom, int n, const float *rays6, float *out8);
+/* calculateJitteredDirectionHemisphere, src/interactions.h:46-85: dead code in the reference (JITTERED_SAMPLING 0, its call site does not
+ * compile) and on no path here; a known-answer entry point only.  Per sample: a normal and (iter, index, depth), which seed the engine as
+ * makeSeededRandomEngine does (src/pathtrace.cu:62-66); out3 = the direction. */
+int ptx_kat_jittered_hemisphere(ptx_tracer *t, int n, const float *normals3, const int32_t *seeds3, int max_iter, float *out3);
 int ptx_kat_compute_intersections(ptx_tracer *t, int n, const void *paths44, void *isects32);
 /* computeIntersections (src/pathtrace.cu:261-344) through the functions the bounce kernels really run -- candidate masks from the
  * world boxes, the tile's (ray, geom) pairs tested by the key functions, 64-bit minimum, winner decoded (split != 0: the three

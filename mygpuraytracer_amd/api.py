@@ -216,6 +216,7 @@ def load_library():
     L.ptx_kat_geom_test.restype, L.ptx_kat_geom_test.argtypes = i, [vp, i, i, vp, vp]
     L.ptx_kat_compute_intersections.restype, L.ptx_kat_compute_intersections.argtypes = i, [vp, i, vp, vp]
     L.ptx_kat_obj_tri_test.restype, L.ptx_kat_obj_tri_test.argtypes = i, [vp, i, i, vp, vp]
+    L.ptx_kat_jittered_hemisphere.restype, L.ptx_kat_jittered_hemisphere.argtypes = i, [vp, i, vp, vp, i, vp]
     L.ptx_kat_tile_intersect.restype, L.ptx_kat_tile_intersect.argtypes = i, [vp, i, vp, vp, i]
     L.ptx_kat_shade.restype, L.ptx_kat_shade.argtypes = i, [vp, i, i, vp, vp, vp]
     L.ptx_kat_generate.restype, L.ptx_kat_generate.argtypes = i, [vp, i, vp]
@@ -682,6 +683,15 @@ class Tracer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((len(rays), 8), np.float32)
         _check(self.lib.ptx_kat_obj_tri_test(self.h, gi, len(rays), _ptr(rays), _ptr(out)), "ptx_kat_obj_tri_test")
+        return out
+
+    def jittered_hemisphere(self, normals, seeds, max_iter=5000):
+        """calculateJitteredDirectionHemisphere of the reference (src/interactions.h:46-85, dead code there): (n, 3) normals and (n, 3) int
+        (iter, index, depth) -> (n, 3) directions"""
+        normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        seeds = np.ascontiguousarray(seeds, np.int32).reshape(-1, 3)
+        out = np.zeros((len(normals), 3), np.float32)
+        _check(self.lib.ptx_kat_jittered_hemisphere(self.h, len(normals), _ptr(normals), _ptr(seeds), int(max_iter), _ptr(out)), "ptx_kat_jittered_hemisphere")
         return out
 
     def compute_intersections(self, paths):

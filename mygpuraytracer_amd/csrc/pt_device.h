@@ -1452,6 +1452,32 @@ PT_DEV vec3 randomDirectionInHemisphere(vec3 normal, Rng &rng) {
     return add(add(a, b), c);
 }
 
+// calculateJitteredDirectionHemisphere, src/interactions.h:46-85 -- DEAD CODE in the reference (JITTERED_SAMPLING 0; its call site does
+// not compile) and on no path here: a known-answer function for SURVEY 8(a13) (ptx_kat_jittered_hemisphere; goldens produced by calling
+// the reference's own function, tests/golden/jitter_kat.npz).  The sampler above on a stratified (iter % n, iter / n) cell.
+PT_DEV vec3 jitteredDirectionInHemisphere(vec3 normal, Rng &rng, int iter, int max_iter) {
+    const int sqrtVal = (int)(pt_sqrt((float)max_iter) + 0.5f);
+    const float invSqrtVal = 1.f / (float)sqrtVal;
+    const int x = iter % sqrtVal;
+    const int y = (int)((float)iter / (float)sqrtVal);
+    float x_point = ((float)x + rng.uniform(0.f, 1.f)) * invSqrtVal;
+    x_point = fmin_glm(fmax_glm(x_point, 0.f), 1.f) ;
+    float y_point = ((float)y + rng.uniform(0.f, 1.f)) * invSqrtVal;
+    y_point = fmin_glm(fmax_glm(y_point, 0.f), 1.f);
+    const float up = pt_sqrt(y_point);
+    const float over = pt_sqrt(1.f - (up * up));
+    const float around = x_point * PT_TWO_PI;
+    vec3 notNormal;
+    if (__builtin_fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) notNormal = V3(1, 0, 0);
+    else if (__builtin_fabsf(normal.y) < PT_SQRT_OF_ONE_THIRD) notNormal = V3(0, 1, 0);
+    else notNormal = V3(0, 0, 1);
+    const vec3 perp1 = normalize(cross(normal, notNormal));
+    const vec3 perp2 = normalize(cross(normal, perp1));
+    float sn, cs;
+    sincos_pt(around, &sn, &cs);
+    return add(add(scale(normal, up), scale(perp1, cs * over)), scale(perp2, sn * over));
+}
+
 // glm reflect: I - N * dot(N, I) * 2
 PT_DEV vec3 reflect(vec3 I, vec3 N) { return sub(I, scale(scale(N, dot(N, I)), 2.0f)); }
 // glm refract (func_geometric.inl:190-197)

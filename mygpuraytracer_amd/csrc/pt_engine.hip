@@ -1813,6 +1813,15 @@ __global__ void k_kat_obj_tri(DScene sc, int gi, int n, const float *rays, float
     o[0] = t; o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = nrm.x; o[5] = nrm.y; o[6] = nrm.z; o[7] = outside ? 1.f : 0.f;
 }
 
+// the reference's dead calculateJitteredDirectionHemisphere (src/interactions.h:46-85): normal + (iter, index, depth) -> direction
+__global__ void k_kat_jittered(int n, const float *normals, const int32_t *seeds, int max_iter, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng; rng.seed(seeds[i * 3], seeds[i * 3 + 1], seeds[i * 3 + 2]);
+    const vec3 d = jitteredDirectionInHemisphere(ld3(normals + i * 3), rng, seeds[i * 3], max_iter);
+    out[i * 3] = d.x; out[i * 3 + 1] = d.y; out[i * 3 + 2] = d.z;
+}
+
 __global__ void k_kat_intersect(DScene sc, int n, const HostPath *paths, HostIsect *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1976,6 +1985,7 @@ struct KernelSet {
     void (*kat_geom)(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out);
     void (*kat_intersect)(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out);
     void (*kat_obj_tri)(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out);
+    void (*kat_jittered)(dim3 grid, hipStream_t st, int n, const float *normals, const int32_t *seeds, int max_iter, float *out);
     void (*kat_tile)(int split, dim3 grid, size_t lds, hipStream_t st, const void *sc, const void *scg, int n, const void *paths, void *out, int uses_uv);
     void (*kat_shade)(dim3 grid, hipStream_t st, const void *scene, int iter, int n, const int32_t *idx, const void *isects, void *paths);
     void (*kat_generate)(dim3 grid, hipStream_t st, const void *cam, int iter, int traceDepth, int aa, int dof, void *paths);
@@ -2015,6 +2025,9 @@ void ks_kat_geom(dim3 grid, hipStream_t st, const void *scene, int gi, int n, co
 void ks_kat_obj_tri(dim3 grid, hipStream_t st, const void *scene, int gi, int n, const float *rays, float *out) {
     hipLaunchKernelGGL(k_kat_obj_tri, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), gi, n, rays, out);
 }
+void ks_kat_jittered(dim3 grid, hipStream_t st, int n, const float *normals, const int32_t *seeds, int max_iter, float *out) {
+    hipLaunchKernelGGL(k_kat_jittered, grid, dim3(256), 0, st, n, normals, seeds, max_iter, out);
+}
 void ks_kat_intersect(dim3 grid, hipStream_t st, const void *scene, int n, const void *paths, void *out) {
     hipLaunchKernelGGL(k_kat_intersect, grid, dim3(256), 0, st, *static_cast<const DScene *>(scene), n, static_cast<const HostPath *>(paths), static_cast<HostIsect *>(out));
 }
@@ -2032,7 +2045,7 @@ void ks_kat_generate(dim3 grid, hipStream_t st, const void *cam, int iter, int t
 void ks_kat_libm(dim3 grid, hipStream_t st, int n, const float *x, float *s, float *c, const double *pw, double *p5, const float *pxy, float *pout) {
     hipLaunchKernelGGL(k_kat_libm, grid, dim3(256), 0, st, n, x, s, c, pw, p5, pxy, pout);
 }
-const KernelSet g_kernels_here = {PT_ARITH, ks_bounce, ks_mesh, ks_finish, ks_kat_geom, ks_kat_intersect, ks_kat_obj_tri, ks_kat_tile, ks_kat_shade, ks_kat_generate, ks_kat_libm};
+const KernelSet g_kernels_here = {PT_ARITH, ks_bounce, ks_mesh, ks_finish, ks_kat_geom, ks_kat_intersect, ks_kat_obj_tri, ks_kat_jittered, ks_kat_tile, ks_kat_shade, ks_kat_generate, ks_kat_libm};
 
 }  // namespace
 
@@ -3544,6 +3557,20 @@ int ptx_kat_obj_tri_test(ptx_tracer *t, int geom, int n, const float *rays6, flo
     { const DScene sc = t->scene(); t->ks->kat_obj_tri(dim3((n + 255) / 256), t->stream, &sc, geom, n, d_in.p, d_out.p); }
     HIPCHECK(hipStreamSynchronize(t->stream));
     HIPCHECK(hipMemcpy(out8, d_out, sizeof(float) * 8 * (size_t)n, hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_kat_jittered_hemisphere(ptx_tracer *t, int n, const float *normals3, const int32_t *seeds3, int max_iter, float *out3) {
+    KAT_PROLOGUE
+    if (n <= 0) return PTX_OK;
+    if (max_iter < 1) return set_error(PTX_ERR_INVALID, "max_iter must be >= 1");
+    DevBuf<float> d_n, d_o; DevBuf<int32_t> d_s;
+    HIPCHECK(hipMalloc(&d_n.p, 12 * (size_t)n)); HIPCHECK(hipMalloc(&d_o.p, 12 * (size_t)n)); HIPCHECK(hipMalloc(&d_s.p, 12 * (size_t)n));
+    HIPCHECK(hipMemcpy(d_n, normals3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_s, seeds3, 12 * (size_t)n, hipMemcpyHostToDevice));
+    t->ks->kat_jittered(dim3((n + 255) / 256), t->stream, n, d_n.p, d_s.p, max_iter, d_o.p);
+    HIPCHECK(hipStreamSynchronize(t->stream));
+    HIPCHECK(hipMemcpy(out3, d_o, 12 * (size_t)n, hipMemcpyDeviceToHost));
     return PTX_OK;
 }
 

@@ -655,6 +655,42 @@ static v3 calculateRandomDirectionInHemisphere(v3 normal, o_rng *rng) {
     return add3(add3(a, b), d);
 }
 
+/* calculateJitteredDirectionHemisphere, src/interactions.h:46-85 -- DEAD CODE in the reference (JITTERED_SAMPLING 0, :5; the block that
+ * would call it, :243-251, does not even compile: it names variables scatterRay does not have).  The function itself compiles, so it is
+ * restated for SURVEY 8(a13) as a known-answer function only; nothing on the path calls it.  A stratified variant of the sampler above:
+ * cell (iter % n, iter / n) of an n x n grid over the unit square, n = round(sqrt(max_iter)), jittered inside the cell. */
+static v3 calculateJitteredDirectionHemisphere(v3 normal, o_rng *rng, int iter, int max_iter) {
+    int samples = max_iter;
+    int sqrtVal = (int)(sqrtf((float)samples) + 0.5f);
+    float invSqrtVal = 1.f / (float)sqrtVal;
+    int x = iter % sqrtVal;
+    int y = (int)((float)(iter) / (float)sqrtVal);
+    float x_point = (float)x + rng_uniform(rng, 0, 1);
+    x_point = x_point * invSqrtVal;
+    x_point = x_point < 0.f ? 0.f : x_point; x_point = 1.f < x_point ? 1.f : x_point;      /* glm::clamp = min(max(x, 0), 1) */
+    float y_point = (float)y + rng_uniform(rng, 0, 1);
+    y_point = y_point * invSqrtVal;
+    y_point = y_point < 0.f ? 0.f : y_point; y_point = 1.f < y_point ? 1.f : y_point;
+    float up = sqrtf(y_point);
+    float over = sqrtf(1.f - (up * up));
+    float around = x_point * O_TWO_PI;
+    v3 directionNotNormal;
+    if (fabsf(normal.x) < O_SQRT_OF_ONE_THIRD) directionNotNormal = V3(1, 0, 0);
+    else if (fabsf(normal.y) < O_SQRT_OF_ONE_THIRD) directionNotNormal = V3(0, 1, 0);
+    else directionNotNormal = V3(0, 0, 1);
+    v3 perpendicularDirection1 = normalize3(cross3(normal, directionNotNormal));
+    v3 perpendicularDirection2 = normalize3(cross3(normal, perpendicularDirection1));
+    float c = lm_cosf(around), sn = lm_sinf(around);
+    return add3(add3(scale3(normal, up), scale3(perpendicularDirection1, c * over)), scale3(perpendicularDirection2, sn * over));
+}
+/* per sample: normal(3) in, (iter, index, depth) seed the engine as makeSeededRandomEngine does, direction(3) out */
+void o_jittered_test(int n, const float *normals3, const int *seeds3, int max_iter, float *out3) {
+    for (int i = 0; i < n; i++) {
+        o_rng r = make_seeded_engine(seeds3[i * 3], seeds3[i * 3 + 1], seeds3[i * 3 + 2]);
+        st3(out3 + i * 3, calculateJitteredDirectionHemisphere(ld3(normals3 + i * 3), &r, seeds3[i * 3], max_iter));
+    }
+}
+
 /* glm reflect: I - N * dot(N, I) * 2   (func_geometric.inl:175-178) */
 static inline v3 reflect3(v3 I, v3 N) { return sub3(I, scale3(scale3(N, dot3(N, I)), 2.0f)); }
 /* glm refract (func_geometric.inl:190-197) */

@@ -82,6 +82,8 @@ void o_scene_set_tile(void *s, int rows, int rank, int world);   /* multi-GPU ro
 void o_geom_test(void *s, int gi, int n, const float *rays6, float *out10);
 /* objTriIntersectionTest / triangleIntersectionLocalTest (src/intersections.h:175-205, 284-315: dead code in the reference) */
 void o_obj_tri_test(void *s, int gi, int n, const float *rays6, float *out8);
+/* calculateJitteredDirectionHemisphere (src/interactions.h:46-85: dead code in the reference) */
+void o_jittered_test(int n, const float *normals3, const int *seeds3, int max_iter, float *out3);
 void o_compute_intersections(void *s, int n, const o_path *paths, o_isect *out);
 void o_shade(void *s, int iter, int depth, int n, const int *idx, const o_isect *isects, o_path *paths);
 

@@ -248,6 +248,18 @@ void ref_geom_test(void *h, int gi, int n, const float *rays, float *out) {
     }
 }
 
+// the reference's dead calculateJitteredDirectionHemisphere (src/interactions.h:46-85), called as it stands; the engine is seeded as
+// makeSeededRandomEngine does (iter, index, depth per sample) and `iter` is the sample's own
+void ref_jittered_test(int n, const float *normals, const int *seeds, int max_iter, float *out) {
+    for (int i = 0; i < n; i++) {
+        thrust::default_random_engine rng = makeSeededRandomEngine(seeds[i * 3], seeds[i * 3 + 1], seeds[i * 3 + 2]);
+        glm::vec3 nrm;
+        memcpy(&nrm, normals + i * 3, 12);
+        const glm::vec3 d = calculateJitteredDirectionHemisphere(nrm, rng, seeds[i * 3], max_iter);
+        memcpy(out + i * 3, &d, 12);
+    }
+}
+
 // the reference's dead pair (src/intersections.h:175-205, 284-315), called as it stands.  out per ray: t, point(3), normal(3), outside
 void ref_obj_tri_test(void *h, int gi, int n, const float *rays, float *out) {
     RefState *st = (RefState *)h;

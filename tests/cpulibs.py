@@ -61,6 +61,7 @@ class _Tracer:
             "rng_uniform": (None, [i, i, i, f, f, i, vp]),
             "geom_test": (None, [vp, i, i, vp, vp]),
             "obj_tri_test": (None, [vp, i, i, vp, vp]),
+            "jittered_test": (None, [i, vp, vp, i, vp]),
             "compute_intersections": (None, [vp, i, vp, vp]),
             "shade": (None, [vp, i, i, i, vp, vp, vp]),
             "pt_init": (None, [vp]),
@@ -106,6 +107,15 @@ class _Tracer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         out = np.zeros((len(rays), 8), np.float32)
         self._f("obj_tri_test")(self.h, gi, len(rays), _ptr(rays), _ptr(out))
+        return out
+
+    def jittered_test(self, normals, seeds, max_iter=5000):
+        """calculateJitteredDirectionHemisphere (src/interactions.h:46-85, dead code of the reference): (n, 3) normals, (n, 3) int
+        (iter, index, depth) -> (n, 3) directions"""
+        normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        seeds = np.ascontiguousarray(seeds, np.int32).reshape(-1, 3)
+        out = np.zeros((len(normals), 3), np.float32)
+        self._f("jittered_test")(len(normals), _ptr(normals), _ptr(seeds), int(max_iter), _ptr(out))
         return out
 
     def compute_intersections(self, paths):

@@ -41,6 +41,8 @@ PROVENANCE = {
     "loader_": "direct",                 # Scene::Scene / loadGeom / loadObj / loadCamera of src/scene.cpp; the post-runCuda camera
                                          # inside the same files is restated (main.cpp needs GL)
     "isect_kat_": "direct",              # boxIntersectionTest / sphereIntersectionTest / meshIntersectionTest themselves
+    "jitter_kat": "direct",              # calculateJitteredDirectionHemisphere (src/interactions.h:46-85), dead code in the reference, called
+                                         # as it stands; the engine's seed formula is the restated three lines of rng_kat
     "dead_tri_kat": "direct",            # objTriIntersectionTest -> triangleIntersectionLocalTest (src/intersections.h:175-205, 284-315), dead
                                          # code in the reference, called as it stands
     "shade_kat_": "direct+restated",     # scatterRay itself, inside the restated body of shadeFakeMaterial; inputs captured mid-render
@@ -170,6 +172,24 @@ def dead_tri(R):
     np.savez_compressed(os.path.join(HERE, "dead_tri_kat.npz"), **out)
     for k in ("obj", "cottage"):
         print(k, "accepted", int((out[k + "_out"][:, 0] > 0).sum()), "of", len(out[k + "_rays"]))
+
+
+def jitter(R):
+    """calculateJitteredDirectionHemisphere (src/interactions.h:46-85) of the reference, called directly: 4096 random unit normals (all
+    three branches of the not-normal choice; a few axis-aligned), iterations across and beyond the 5000 of the scene files, both a
+    square and a non-square max_iter."""
+    rng = np.random.default_rng(20261006)
+    n = 4096
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[:6] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    seeds = np.stack([rng.integers(1, 6000, n), rng.integers(0, 1920 * 1080, n), rng.integers(0, 9, n)], 1).astype(np.int32)
+    seeds[:4, 0] = [1, 70, 4999, 5000]
+    out = dict(normals=nrm.astype(np.float32), seeds=seeds)
+    for mi in (5000, 64):
+        out["dir_%d" % mi] = R.jittered_test(out["normals"], seeds, mi)
+    np.savez_compressed(os.path.join(HERE, "jitter_kat.npz"), **out)
+    print("jitter_kat.npz:", n, "samples; |d| in", float(np.linalg.norm(out["dir_5000"], axis=1).min()), float(np.linalg.norm(out["dir_5000"], axis=1).max()))
 
 
 def png_textures(R):
@@ -351,6 +371,9 @@ def main():
         return
     if sys.argv[1:] == ["dead_tri"]:
         dead_tri(RefLib(so))
+        return
+    if sys.argv[1:] == ["jitter"]:
+        jitter(RefLib(so))
         return
     R = RefLib(so)
     rng = np.random.default_rng(20261004)

@@ -145,6 +145,20 @@ def test_dead_triangle_functions_on_device(gpu_product, O):
     T.close(); Tc.close()
 
 
+def test_dead_jittered_sampler_on_device(gpu_product, O):
+    """calculateJitteredDirectionHemisphere (src/interactions.h:46-85; dead code in the reference, on no path here) as a
+    device function behind ptx_kat_jittered_hemisphere: bit-identical to the oracle in the kernels' libm mode, and within 1 ulp of what
+    the reference's own function returned ([direct] fixture jitter_kat.npz; glibc's sinf / cosf there, the portable ones here)."""
+    k = golden("jitter_kat.npz")
+    s, T = make_pair(gpu_product, O, "sphere.txt", (16, 16), 2)
+    for mi in (5000, 64):
+        got = T.jittered_hemisphere(k["normals"], k["seeds"], mi)
+        assert beq(got, O.jittered_test(k["normals"], k["seeds"], mi))          # (O: libm mode 1, the routines the kernels run)
+        want = k["dir_%d" % mi]
+        assert np.abs(got - want).max() <= 2 * np.finfo(np.float32).eps and (got == want).mean() > 0.9
+    T.close()
+
+
 @pytest.mark.parametrize("scene,res,depth,opt", [
     ("sphere.txt", (64, 64), 4, {}),
     ("cornell.txt", (64, 64), 8, dict(antialiasing=0)),

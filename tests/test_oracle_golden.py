@@ -79,6 +79,20 @@ def test_dead_triangle_functions(O, which, loader):
     assert beq(out[hit], ref[hit])
 
 
+def test_dead_jittered_sampler(O):
+    """calculateJitteredDirectionHemisphere (src/interactions.h:46-85), dead code in the reference (JITTERED_SAMPLING 0; the
+    block that would call it does not compile) and on no path here: the oracle's restatement against what the reference's own function
+    returned for 4096 (normal, iteration, stream index, depth) samples, max_iter 5000 and 64 ([direct] fixture jitter_kat.npz).  glibc
+    mode, as the reference's host pass; the portable sin / cos the kernels run stay within 1 ulp of it."""
+    k = golden("jitter_kat.npz")
+    for mi in (5000, 64):
+        O.set_libm(0)
+        assert beq(O.jittered_test(k["normals"], k["seeds"], mi), k["dir_%d" % mi])
+        O.set_libm(1)
+        assert np.abs(O.jittered_test(k["normals"], k["seeds"], mi) - k["dir_%d" % mi]).max() <= 2 * np.finfo(np.float32).eps
+        O.set_libm(0)
+
+
 def _scene_for_shade(O, tag):
     from test_loader import product_dump_from_text      # mirror scenes exist only as text: load with the product loader
     k = golden("shade_kat_%s.npz" % tag)

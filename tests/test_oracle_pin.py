@@ -132,3 +132,15 @@ def test_dead_triangle_functions_live(ref_lib, oracle_lib):
     assert (a[:, 0] > 0).sum() > 2000
     assert beq(a, b)
 
+
+def test_dead_jittered_sampler_live(ref_lib, oracle_lib):
+    """SURVEY 8(a13) on fresh samples: the reference's own calculateJitteredDirectionHemisphere (src/interactions.h:46-85, dead code
+    there) against the oracle's restatement, 50 000 samples, three values of max_iter -- bit for bit (glibc mode)."""
+    rng = np.random.default_rng(78)
+    n = 50000
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    seeds = np.stack([rng.integers(1, 20000, n), rng.integers(0, 3840 * 2160, n), rng.integers(0, 13, n)], 1).astype(np.int32)
+    oracle_lib.set_libm(0)
+    for mi in (5000, 1, 1000):
+        assert beq(ref_lib.jittered_test(nrm, seeds, mi), oracle_lib.jittered_test(nrm, seeds, mi))
+
