@@ -79,8 +79,9 @@ constexpr int MAX_LANES = 8;     // launch sets in flight at most (ptx_options.l
                               // LDS is also what a CU holds with the Cornell tables since the record buffer lost a row and the window half its runs)
 #endif
 #ifndef PT_FAST_WAVES_FIRST
-#define PT_FAST_WAVES_FIRST 8      // the specialised camera-ray variant: 64 registers since round 5 (two values spill to scratch: the kernel alone +3 %, the wall with
-                                    // three launch sets in flight -0.8 %, three runs each on one box, gpurun_out/r5i_ab.log)
+#define PT_FAST_WAVES_FIRST (PT_FAST_WAVES - 1)      // the specialised camera-ray variant: 64-66 registers.  (Compiled for 8 waves it fits 64 with two
+                                    // values spilled to scratch: the kernel alone +3 %, the wall with three launch sets in flight -0.8 %, three runs
+                                    // each on one box, gpurun_out/r5i_ab.log -- not taken: no kernel of the path spills, tests/test_build_resources.py)
 #endif
 #ifndef PT_FAST_WAVES_SPLIT
 #define PT_FAST_WAVES_SPLIT 4 // same for the specialised MODE 1 variant, which carries the mesh candidate queue as well
