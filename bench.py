@@ -36,13 +36,19 @@ CONTRACT_BYTES_BOUNCE_KERNEL = 76 + 120
 CONTRACT_BYTES_LOOP = 436
 
 
-def own_layout_bytes(rpb, with_direction=1.0, with_normal=1.0):
+LIT_SHARE_OF_ENDED = 0.05      # share of the paths that END at a bounce >= 1 whose end carries radiance (a light hit): 0.047 on C4, 0.059 on C5
+                                # (counted with the CPU oracle at 480x270, three iterations: DESIGN.md 6); the others end black and move nothing
+
+
+def own_layout_bytes(rpb, with_direction=1.0, with_normal=1.0, index_bytes=4):
     """Algorithmic bytes per ray of k_bounce (bounces >= 1) by THIS design's data layout, from the rays per bounce and the
     run's own record mix (ptx_stats: the share of stored paths whose record carries a direction / a normal rather than a 3-bit code):
     a record is two 16-byte quads (shading point + pixel slot, throughput colour + material|geom), a third with the normal (+ texcoord u)
-    and a fourth with the incoming direction (+ texcoord v) where the next bounce can need them.  A ray entering bounce b reads its
-    local-index entry (8 B) and its record; if it is stored for bounce b + 1 it writes its record, its 4-B key and, in the kernel's tail,
-    its 8-B local-index entry (re-reading the key: 4 B); otherwise it writes 12 B of radiance and the 4-B empty key."""
+    and a fourth with the incoming direction (+ texcoord v) where the next bounce can need them.  Round 5: a ray entering bounce b reads
+    its local-index entry (ONE word where chunks are <= 128 tiles: every configuration the bench runs; 8 B otherwise) and its record; if it
+    is stored for bounce b + 1 it writes its record, its 4-B key and, in the kernel's tail, its 4-B local-index entry (re-reading the key:
+    4 B); a path that ends writes 12 B of radiance + 1 flag byte if it ends on a light, and NOTHING if it ends black (rounds 3-4: 12 B of
+    zeros and a 4-B "no record" key for every ended path, 8-B index entries)."""
     n = [float(x) for x in rpb] + [0.0]
     tot = sum(n[1:-1])
     if tot <= 0:
@@ -51,7 +57,7 @@ def own_layout_bytes(rpb, with_direction=1.0, with_normal=1.0):
     b = 0.0
     for k in range(1, len(n) - 1):
         stored = n[k + 1]
-        b += n[k] * (8 + rec) + stored * (rec + 4 + 8 + 4) + (n[k] - stored) * (12 + 4)
+        b += n[k] * (index_bytes + rec) + stored * (rec + 4 + index_bytes + 4) + (n[k] - stored) * LIT_SHARE_OF_ENDED * 13.0
     return b / tot
 
 
@@ -612,7 +618,7 @@ def main():
     f_dir = (st2.get("stored_with_direction", 0) - st.get("stored_with_direction", 0)) / sp if sp else 1.0
     f_nrm = 1.0 - (st2.get("stored_with_normal_code", 0) - st.get("stored_with_normal_code", 0)) / sp if sp else 1.0
     rec_bytes = 32.0 + 16.0 * f_nrm + 16.0 * f_dir
-    own_bytes = own_layout_bytes(rpb, f_dir, f_nrm) if dominant == "k_bounce" else 8.0 + rec_bytes + 4 + 8 + 4      # (first bounce: nothing read, mostly stored)
+    own_bytes = own_layout_bytes(rpb, f_dir, f_nrm) if dominant == "k_bounce" else rec_bytes + 4 + 4 + 4      # (first bounce: nothing read, mostly stored)
     achieved = own_bytes * units / avg_s if avg_s > 0 else 0.0
     contract = CONTRACT_BYTES_BOUNCE_KERNEL * units / avg_s if avg_s > 0 else 0.0
     # HBM bytes and instruction counts per launch come from PMC counters, which need rocprofv3: they are NOT measured in this run but
@@ -694,8 +700,8 @@ def main():
     loop_contract = CONTRACT_BYTES_LOOP * rays / (loop_ms * 1e-3) if loop_ms > 0 else 0.0
     # One read tells what bounds the kernel: `bound` names it (vector-instruction issue -- valu_issue.frac of the issue peak), achieved /
     # frac / traffic are the HBM side of the same launches by this design's own bytes; the contract's record sizes are under contract_*.
-    roofline = dict(schema="r3+: achieved / frac / algorithmic_bytes_per_unit are THIS design's own layout bytes (r3: ~120 B per ray; since the end of r4 ~85: records "
-                           "of 32-64 B by what the next bounce can need, record_bytes); rounds 1-2 put the "
+    roofline = dict(schema="r3+: achieved / frac / algorithmic_bytes_per_unit are THIS design's own layout bytes (r3: ~120 B per ray; end of r4 ~85: records "
+                           "of 32-64 B by what the next bounce can need, record_bytes; r5 ~71: one-word index entries, no zeros for paths that end black); rounds 1-2 put the "
                            "contract's 196 B there, which now lives under contract_196B_frac -- BENCH_r02's frac compares with contract_196B_frac, not with frac",
                     measured_in_this_run=["achieved", "frac", "avg_launch_us", "launches", "units_per_launch", "kernels_ms_per_step", "contract_*", "loop_ms_per_step"],
                     from_committed_profiles=["traffic", "traffic_over_algorithmic", "physical_frac", "physical_frac_wall (bytes; the time is this run's)", "valu_issue", "bound"], profiles=profiles_stale,
