@@ -562,6 +562,8 @@ def main():
 
         def c5_create():
             nonlocal T5, img5, warm5
+            if os.environ.get("PTX_BENCH_FAIL_C5_RANK") == str(rank):      # rehearsal of the failure protocol (tools/runs/r5reh.sh): this rank's phase fails
+                raise RuntimeError("PTX_BENCH_FAIL_C5_RANK: rehearsed failure of the tracer's creation on rank %d" % rank)
             s5 = pt.Scene(os.path.join(ROOT, "scenes", "cornellSpaceship20k.txt"), res=C5RES, depth=8)
             s5.apply_runcuda_camera()
             img5 = multigpu.frame_buffer(C5RES[0], C5RES[1], world, device)
