@@ -1781,3 +1781,45 @@ def test_several_devices_apps_variant(gpu_product, O):
         M.render(1, 3)
         assert beq(M.read_image(), img)
         assert beq(M.read_albedo(), alb)
+
+
+@pytest.mark.parametrize("scene,opt", [("cornellObj.txt", {}), ("cornell.txt", dict(antialiasing=0)), ("cornellSpaceship.txt", dict(depth_of_field=1))])
+def test_small_memory_budget_changes_nothing_but_the_batch(gpu_product, monkeypatch, scene, opt):
+    """ptx_create sizes its launch sets to a quarter of what the device has (hipMemGetInfo; round 5: a CPX / NPS partition or a shared GPU
+    must not be refused where a smaller batch runs) -- PTX_DEBUG_MEM_BUDGET_MB stands in for a small device.  Iterations per set only
+    decide how much is in flight: the frame, the ray counts and the fences are those of the default."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(192, 108), depth=6)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s, **opt) as T:
+        T.render(1, 30)
+        want, st = T.read_image(), T.stats()
+    monkeypatch.setenv("PTX_DEBUG_MEM_BUDGET_MB", "8")           # 8 MB for all streams in flight: one or two iterations per set
+    with pt.Tracer(s, **opt) as T:
+        T.render(1, 30)
+        assert beq(T.read_image(), want)
+        st2 = T.stats()
+        assert st2["rays_total"] == st["rays_total"] and st2["fenced"] == 0
+
+
+def test_sized_stats_never_write_past_what_the_caller_has(gpu_product):
+    """ptx_get_stats_sized (round 5: ptx_stats grew in round 4 and will again): a caller compiled against a shorter struct passes ITS
+    size and gets that prefix; a longer one gets zeros behind the library's struct; ptx_abi_version / ptx_sizeof_* say what the library has."""
+    import ctypes as C
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "sphere.txt"), res=(32, 32), depth=3)
+    s.apply_runcuda_camera()
+    with pt.Tracer(s) as T:
+        T.render(1, 3)
+        full = T.stats()
+        n = C.sizeof(pt.api.Stats)
+        assert T.lib.ptx_sizeof_stats() == n and T.lib.ptx_abi_version() == pt.api.ABI_VERSION
+        for size in (8 + 64 * 8 + 8, n, n + 64):                 # up to rays_total; exactly; a caller from the future
+            buf = (C.c_uint8 * (n + 128))(*([0xA5] * (n + 128)))
+            assert T.lib.ptx_get_stats_sized(T.h, buf, size) == 0
+            raw = bytes(buf)
+            assert raw[size:] == bytes([0xA5]) * (n + 128 - size)                # nothing behind what the caller said it has
+            got = pt.api.Stats.from_buffer_copy(raw[:n] if size >= n else raw[:size] + bytes(n - size))
+            assert got.bounces == full["bounces"] and int(got.rays_total) == full["rays_total"]
+            if size > n:
+                assert raw[n:size] == bytes(size - n)
