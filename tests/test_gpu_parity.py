@@ -1823,3 +1823,28 @@ def test_sized_stats_never_write_past_what_the_caller_has(gpu_product):
             assert got.bounces == full["bounces"] and int(got.rays_total) == full["rays_total"]
             if size > n:
                 assert raw[n:size] == bytes(size - n)
+
+
+@pytest.mark.parametrize("scene,opt", [("cornellObj.txt", {}), ("cornell.txt", dict(antialiasing=0)), ("cornellSpaceship20k.txt", dict(depth_of_field=1))])
+def test_both_forms_of_the_local_index(gpu_product, O, monkeypatch, scene, opt):
+    """The chunk-local sorted index is one word per stored path (16-bit slot distance | 16-bit rank) where no workgroup's chunk passes 128
+    tiles, two words otherwise (8K frames with few iterations per set); PTX_DEBUG_NO_IDX16 forces the two-word form.  Same order either
+    way: frames equal the oracle's in both, with the first-bounce cache (whose stage keeps the form it was written in) and the split mesh search."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", scene), res=(128, 72), depth=6)
+    s.apply_runcuda_camera()
+    d = s.dump()
+    O.set_libm(1); O.create(d, d["textures"])
+    O.set_options(aa=opt.get("antialiasing", 1), dof=opt.get("depth_of_field", 0), sort=1, cache=1)
+    O.pt_init()
+    for it in range(1, 5):
+        O.iterate(it)
+    frames = []
+    for no16 in (False, True):
+        if no16:
+            monkeypatch.setenv("PTX_DEBUG_NO_IDX16", "1")
+        with pt.Tracer(s, **opt) as T:
+            T.render(1, 4)
+            frames.append(T.read_image())
+            assert T.stats()["fenced"] == 0
+    assert beq(frames[0], O.image()) and beq(frames[1], O.image())
