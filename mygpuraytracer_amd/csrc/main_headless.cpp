@@ -4,7 +4,7 @@
 // save <FILE>.<utc>.<n>samp.png with saveImage's mirroring (main.cpp:81-102).
 //
 //   mi355x_pathtrace SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr]
-//                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K]
+//                                  [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--arith 0|1|2]   (ptx_options.arith: 0 exact, the default)
 //                                  [--checkpoint FILE [--checkpoint-every N]] [--resume FILE]
 //                                  [--orbit "left:DX,DY;right:DY;middle:DX,DY;space"]   (the mouse of main.cpp:166-212, scripted)
 //                                  [--per-call [--no-render-ahead]]   (one pathtrace(pbo, frame, iter) per iteration with the frame read
@@ -35,7 +35,7 @@ static std::string currentTimeString() {          // src/preview.cpp:13-19
 int main(int argc, char **argv) {
     const std::string startTimeString = currentTimeString();
     if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT] [--per-call [--no-render-ahead]]\n", argv[0]);
+        printf("Usage: %s SCENEFILE.txt [--res W H] [--depth D] [--iterations N] [--out PREFIX] [--pfm] [--hdr] [--no-aa] [--dof] [--no-sort] [--no-cache] [--device K] [--arith 0|1|2] [--checkpoint FILE [--checkpoint-every N]] [--resume FILE] [--orbit SCRIPT] [--per-call [--no-render-ahead]]\n", argv[0]);
         return 1;
     }
     int resw = 0, resh = 0, depth = 0, iterations = 0;
@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
         else if (a == "--iterations") { need(1); iterations = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out_prefix = argv[++i]; }
         else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
+        else if (a == "--arith") { need(1); opt.arith = atoi(argv[++i]); }
         else if (a == "--pfm") pfm = true;
         else if (a == "--hdr") hdr = true;
         else if (a == "--checkpoint") { need(1); ckpt_path = argv[++i]; }

@@ -197,3 +197,23 @@ def test_split_mesh_search_at_the_other_levels(gpu_product, level):
             means[lv] = (T.read_image().astype(np.float64).mean(axis=0) / 24, st["rays_total"])
     assert np.abs(means[level][0] / means[0][0] - 1.0).max() < 0.03
     assert abs(means[level][1] / means[0][1] - 1.0) < 0.01
+
+
+@pytest.mark.parametrize("level", LEVELS)
+def test_full_size_frames_at_the_other_levels(gpu_product, level):
+    """BASELINE config 4 at its own size (1920x1080, depth 8, 24 iterations through ptx_render: three launch sets in flight, the record masks,
+    the one-word local index) from the level's code object: no fenced index, the rays entering every bounce within 0.2 % of the exact level's,
+    the frame's mean radiance within 0.5 %."""
+    pt = gpu_product
+    s = pt.Scene(os.path.join(ROOT, "scenes", "cornellObj.txt"), res=(1920, 1080), depth=8)
+    s.apply_runcuda_camera()
+    got = {}
+    for lv in (0, level):
+        with pt.Tracer(s, arith=lv) as T:
+            T.render(1, 24)
+            st = T.stats()
+            assert st["fenced"] == 0
+            got[lv] = (T.read_image().astype(np.float64).mean(axis=0), st["rays_total"], st["rays_per_bounce"])
+    assert abs(got[level][1] / got[0][1] - 1.0) < 0.002
+    assert all(abs(a - b) <= 0.002 * b + 50 for a, b in zip(got[level][2], got[0][2]))
+    assert np.abs(got[level][0] / got[0][0] - 1.0).max() < 0.005
