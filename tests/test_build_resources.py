@@ -1,7 +1,8 @@
 """CPU: what the compiler made of the kernels (hipcc cross-compiles gfx950 without a GPU; `make resource-usage` =
--Rpass-analysis=kernel-resource-usage on pt_engine.hip).  The specialised bounce kernels are launched as seven workgroups per CU
-and compiled for seven waves per SIMD: a change that pushes them over 72 registers would not fail any parity
-test, it would spill -- this test is where that shows."""
+-Rpass-analysis=kernel-resource-usage on pt_engine.hip).  The specialised bounce kernels are launched as eight (later bounces) and
+twenty (camera bounce) workgroups per CU and compiled for eight / seven waves per SIMD: a change that pushes them over
+64 / 72 registers would not fail any parity test, it would spill -- this test is where that shows.  (Round 5 tried the camera kernel
+at eight waves: it fits 64 registers only with two values in scratch, and this test is why that build was not taken.)"""
 import os
 import re
 import shutil
