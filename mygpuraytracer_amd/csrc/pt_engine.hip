@@ -1720,13 +1720,13 @@ __global__ void k_gather(TileMap tm, int resx, int nseg, size_t seg_part, const 
         int x, y;
         owned_pixel(tm, i, x, y);
         const size_t o = ((size_t)x + (size_t)y * resx) * 3;
-        bool any = false;
-        for (int s = 0; s < nseg; s++) any = any || reinterpret_cast<const uint8_t *>(part + seg_part * s + 3 * (size_t)cap)[i] != 0;
-        if (!any) continue;                              // (a pixel no iteration of the batch lit: its sum does not move)
+        unsigned long long lit = 0;                      // bit s: iteration s of the batch ended this pixel's path on a light (nseg <= 64)
+        for (int s = 0; s < nseg; s++) lit |= (unsigned long long)(reinterpret_cast<const uint8_t *>(part + seg_part * s + 3 * (size_t)cap)[i] != 0) << s;
+        if (!lit) continue;                              // (a pixel no iteration of the batch lit: its sum does not move)
         float r = image[o], g = image[o + 1], b = image[o + 2];
-        for (int s = 0; s < nseg; s++) {
-            const float *ps = part + seg_part * s + (size_t)i * 3;
-            if (reinterpret_cast<const uint8_t *>(part + seg_part * s + 3 * (size_t)cap)[i]) { r += ps[0]; g += ps[1]; b += ps[2]; }
+        for (; lit; lit &= lit - 1) {                    // in iteration order: the same fp32 sums as one iteration at a time
+            const float *ps = part + seg_part * (size_t)(__ffsll((long long)lit) - 1) + (size_t)i * 3;
+            r += ps[0]; g += ps[1]; b += ps[2];
         }
         image[o] = r; image[o + 1] = g; image[o + 2] = b;
     }
